@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Benchmark of the qgemm hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one `flute.qgemm` launch (M=1, W4G64 NF4 table, fp16, K=N=4096 -
+BASELINE.json configs[1], the shape the metric's target is quoted on) over one
+packed weight copy.  Steps rotate over enough distinct (Q, S) copies to exceed
+the 256 MiB Infinity Cache, so every step streams its weights from HBM; inputs
+are resident in HBM before the timed region.  The K steps are enqueued as one
+hipGraph replay (how a decode loop launches them; host launch overhead of the
+Python op is reported separately as `eager_us_per_step`).
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying
+`roofline` (HBM, algorithmic bytes / kernel time from HIP events on the launch
+stream) and `cpu_baseline` (the CPU oracle = the reference's test formula,
+dequant + torch.mm, timed on this host's cores).  N > 1: one process per GPU,
+independent replicas of the same layer (the path has no collective; weak
+scaling), barrier + max-over-ranks timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0          # measured float4 copy
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
+L3_BYTES = 256 * 1024 * 1024
+
+
+def algorithmic_bytes(M, N, K, bits, g):
+    """Q + S + X + Y + tables."""
+    P = bits * N // 16
+    return 2 * P * K + 2 * N * K // g + 2 * M * K + 2 * M * N + 2 * 2 ** bits + 4 * 4 ** bits
+
+
+class Layer:
+    """`copies` independent packed layers of one shape, all resident in HBM."""
+
+    def __init__(self, M, N, K, bits, g, dtype, device, copies, table_values=None, seed=0):
+        import flute_amd
+        from flute_amd import utils
+        self.M, self.N, self.K, self.bits, self.g, self.dtype = M, N, K, bits, g, dtype
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        if table_values is None:
+            table = torch.randn(2 ** bits, generator=gen)
+        else:
+            table = torch.tensor(table_values)
+        self.table = table.to(dtype).to(device)
+        self.table2 = utils.make_qmap2_from_qmap(self.table)
+        self.X = (torch.randn(M, K, generator=gen) / 100).to(dtype).to(device)
+        self.num_sms = utils.get_device_num_sms(device)
+        self.ws = utils.get_workspace_streamk(device)
+        P = bits * N // 16
+        self.Q, self.S = [], []
+        gdev = torch.Generator(device=device).manual_seed(seed)
+        for _ in range(copies):
+            # any bit pattern is a valid packed matrix (all codes reachable for b=2,4;
+            # for b=3 too): uniform int16 == uniform codes
+            self.Q.append(torch.randint(-2 ** 15, 2 ** 15, (P, K), dtype=torch.int16,
+                                        device=device, generator=gdev))
+            self.S.append(torch.randn(N, K // g, device=device, generator=gdev).to(dtype))
+        self.template_id = None
+        self.qgemm = flute_amd.qgemm
+
+    def bytes(self):
+        return algorithmic_bytes(self.M, self.N, self.K, self.bits, self.g)
+
+    def flops(self):
+        return 2 * self.M * self.N * self.K
+
+    def tune(self):
+        from flute_amd import tune
+        self.template_id = tune._tune(self.M, self.N, self.K, self.bits, self.g, self.num_sms,
+                                      self.dtype, self.X.device, num_seeds=1, rep=40)
+        return self.template_id
+
+    def step(self, i):
+        c = i % len(self.Q)
+        return self.qgemm(self.X, self.Q[c], self.S[c], self.table, self.table2, self.ws,
+                          self.bits, self.g, self.template_id, self.num_sms)
+
+
+def copies_for(N, K, bits, cap_bytes=3 << 30):
+    per = 2 * (bits * N // 16) * K
+    n = L3_BYTES // per + 2
+    return int(max(2, min(n, cap_bytes // per)))
+
+
+def time_graph(layer, steps, warmup, sync):
+    """Capture `steps` launches in one hipGraph, replay once, timed by HIP events on
+    the replay stream and by the host clock around sync()."""
+    for i in range(warmup):
+        layer.step(i)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(steps):
+            layer.step(warmup + i)
+    graph.replay()                      # untimed: first replay pays the upload
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    start.record()
+    graph.replay()
+    end.record()
+    torch.cuda.synchronize()
+    sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    return start.elapsed_time(end), wall_ms
+
+
+def time_eager(layer, steps, warmup):
+    for i in range(warmup):
+        layer.step(i)
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for i in range(steps):
+        layer.step(i)
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end)
+
+
+def cpu_baseline(N, K, bits, g, tile_p=32, runs=3):
+    """The reference's CPU-runnable case (BASELINE.json configs[0]): closed-form unpack
+    of Q, LUT dequant, torch.matmul - i.e. the oracle, timed on the host cores."""
+    from oracle import flute_oracle as O
+    import numpy as np
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    dtype = torch.float16
+    rng = np.random.default_rng(0)
+    W = rng.integers(0, 2 ** bits, size=(K, N), dtype=np.uint8)
+    Q = O.pack(W, bits, tile_p)
+    S = torch.randn(N, K // g).to(dtype)
+    table = torch.tensor(O.NF4_VALUES).to(dtype)
+    X = (torch.randn(1, K) / 100).to(dtype)
+    t0 = time.perf_counter()
+    codes = torch.from_numpy(O.unpack(Q, bits, tile_p).astype(np.int64))
+    t_unpack = time.perf_counter() - t0
+
+    def run():
+        W_ = table[codes]
+        S_ = torch.repeat_interleave(S, g, dim=1).T
+        return torch.mm(X, W_ * S_)      # tests/kernel.py:68-71
+
+    run()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    return {
+        "value": round(algorithmic_bytes(1, N, K, bits, g) / t / 1e9, 4), "unit": "GB/s",
+        "cores": cores, "kind": "port",
+        "sample": f"{runs} x (LUT dequant + torch.mm), M=1 K={K} N={N} W{bits}G{g} fp16, codes "
+                  f"pre-unpacked; best {t * 1e3:.1f} ms; closed-form unpack of Q alone "
+                  f"{t_unpack * 1e3:.0f} ms",
+        "ms": round(t * 1e3, 2), "unpack_ms": round(t_unpack * 1e3, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+        def sync():
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+    else:
+        dist = None
+
+        def sync():
+            torch.cuda.synchronize()
+
+    from oracle.flute_oracle import NF4_VALUES
+    M, N, K, bits, g, dtype = 1, 4096, 4096, 4, 64, torch.float16
+    layer = Layer(M, N, K, bits, g, dtype, device, copies_for(N, K, bits), NF4_VALUES, seed=rank)
+    tid = layer.tune()
+    ev_ms, wall_ms = time_graph(layer, args.steps, args.warmup, sync)
+    eager_ms = time_eager(layer, min(args.steps, 500), 10)
+    t = torch.tensor([ev_ms, wall_ms], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ev_ms, wall_ms = t.tolist()
+    ms_per_step = ev_ms / args.steps
+    bytes_step = layer.bytes()
+    value = world * bytes_step / (ms_per_step * 1e-3) / 1e9
+
+    # cache-resident variant (one copy, served by L2 / Infinity Cache)
+    hot = Layer(M, N, K, bits, g, dtype, device, 1, NF4_VALUES, seed=rank)
+    hot.template_id = tid
+    hot_ms, _ = time_graph(hot, args.steps, args.warmup, lambda: torch.cuda.synchronize())
+
+    extras = []
+    if rank == 0 and not args.no_extras:
+        for (n, k) in ((4096, 4096), (11008, 4096)):
+            for m in (1, 16, 256):
+                if (n, k, m) == (4096, 4096, 1):
+                    continue
+                lay = Layer(m, n, k, bits, g, dtype, device, copies_for(n, k, bits), NF4_VALUES)
+                lay.tune()
+                steps = 500 if m < 256 else 200
+                e_ms, _ = time_graph(lay, steps, 20, lambda: torch.cuda.synchronize())
+                us = e_ms / steps * 1e3
+                extras.append({
+                    "workload": f"W4G64 fp16 M={m} K={k} N={n}", "template_id": lay.template_id,
+                    "us": round(us, 3),
+                    "GBps": round(lay.bytes() / us / 1e3, 1),
+                    "TFLOPs": round(lay.flops() / us / 1e6, 2),
+                    "frac_hbm_8TBps": round(lay.bytes() / us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "frac_mfma_2.5PF": round(lay.flops() / us / 1e6 / MFMA_PEAK_TFLOPS, 4),
+                })
+                del lay
+                torch.cuda.empty_cache()
+
+    if rank == 0:
+        achieved = bytes_step / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "qgemm effective GB/s, M=1, W4G64 NF4 fp16, K=N=4096 (Llama-3-8B linear), HBM-cold",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic (random codes/scales, NF4 table, X=randn/100; "
+                    f"{len(layer.Q)} rotating weight copies > 256 MiB L3)",
+            "config": {"workload": "W4G64 NF4 fp16 qgemm, M=1, K=4096, N=4096 (BASELINE configs[1])",
+                       "template_id": tid, "plan": __import__("flute_amd").utils.get_plan(
+                           M, N, K, bits, g, tid, layer.num_sms, dtype),
+                       "launch": "hipGraph replay of all steps",
+                       "parallelism": f"{world} independent replica(s), no collective"},
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac_of_measured_copy_6.29TBps": round(achieved / HBM_COPY_GBPS, 4),
+                "bytes_per_launch": bytes_step,
+                "kernel_us_events": round(ms_per_step * 1e3, 3),
+                "note": "events bracket the graph replay on its stream: includes inter-kernel gaps",
+            },
+            "cache_resident": {"us": round(hot_ms / args.steps * 1e3, 3),
+                               "GBps": round(bytes_step / (hot_ms / args.steps * 1e-3) / 1e9, 1)},
+            "eager_us_per_step": round(eager_ms / min(args.steps, 500) * 1e3, 3),
+            "wall_ms_timed_region": round(wall_ms, 3),
+            "extras": extras,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(N, K, bits, g)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

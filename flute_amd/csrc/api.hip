@@ -1,0 +1,290 @@
+// Host side of the C ABI (include/flute_amd.h): template table, launch planning
+// and dispatch.  Mirrors the role of flute/csrc/qgemm.cpp:39-83 (qgemm_raw) +
+// qgemm_kernel_raw_generated.cu:15-768 (_qgemm_raw's template switch) +
+// qgemm_kernel.hpp:824-939 (qgemm_host), re-thought for gfx950: instead of one
+// Stream-K kernel with 36/144 tile variants there are two kernel families
+// (streaming decode for M <= 8, MFMA above) whose launch geometry is derived
+// from the template's knobs and the problem shape.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/flute_amd.h"
+#include "kernels.h"
+#include "qgemm_decode.h"
+#include "qgemm_mfma.h"
+
+using namespace flute_amd;
+
+namespace {
+
+struct Overrides { int family, m_block, waves, kw, splitk, lut_copies; };
+Overrides g_ovr = {-1, -1, -1, -1, -1, -1};
+
+constexpr int kMaxLds = 160 * 1024;
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// Template id -> knobs.  Enumeration order is the reference's
+// (flute/codegen_utils.py:110-152): SMs_Multiple {1,2,4} x tile {0,1,2} x
+// stages {2,3,4,5} x (b=4 only) QuantMapMode {Vectorized,_32,_16,_8}; tile 0
+// has TileP 64, tiles 1,2 TileP 32, so id -> TileP is identical to the
+// reference table and reference-packed weights keep their id.
+bool decode_template(int bits, int id, flute_template_info* t) {
+    if (bits != 2 && bits != 3 && bits != 4) return false;
+    const int nq = (bits == 4) ? 4 : 1;
+    const int total = 3 * 3 * 4 * nq;
+    if (id < 0 || id >= total) return false;
+    const int q = id % nq;
+    const int st = (id / nq) % 4;
+    const int tile = (id / (nq * 4)) % 3;
+    const int mult = id / (nq * 12);
+    static const int kMult[3] = {1, 2, 4};
+    static const int kThreads[3] = {512, 512, 256};
+    static const int kTileM[3] = {64, 64, 16};
+    static const int kTileP[3] = {64, 32, 32};
+    static const int kCopies[4] = {1, 32, 16, 8};
+    t->num_bits = bits;
+    t->template_id = id;
+    t->sms_multiple = kMult[mult];
+    t->threads = kThreads[tile];
+    t->tile_m = kTileM[tile];
+    t->tile_k = 64;
+    t->tile_p = kTileP[tile];
+    t->stages = 2 + st;
+    // b=2/3 pair tables are 64 B / 256 B: always replicate them 32x
+    t->lut_copies = (bits == 4) ? kCopies[q] : 32;
+    return true;
+}
+
+int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
+              size_t workspace_bytes, flute_plan* p, flute_template_info* tinfo) {
+    if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
+    if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
+    if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
+    flute_template_info t;
+    if (!decode_template(bits, template_id, &t)) return FLUTE_ERR_TEMPLATE_ID;
+    if (bits == 3 && t.tile_p != 32) return FLUTE_ERR_TEMPLATE_ID;   // utils.py:137-139
+    if (tinfo) *tinfo = t;
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    if (M < 1 || N < 1 || K < 1) return FLUTE_ERR_SHAPE;
+    if (N % (J * t.tile_p) || K % 64 || K % group) return FLUTE_ERR_SHAPE;
+    if (num_sms < 1) num_sms = 256;
+    const int lg = ilog2(group);
+    const int units = N / J;
+    const int lines = K / 64;
+
+    memset(p, 0, sizeof(*p));
+    int copies = g_ovr.lut_copies > 0 ? g_ovr.lut_copies : t.lut_copies;
+    if (copies != 1 && copies != 8 && copies != 16 && copies != 32) copies = 32;
+    p->lut_copies = copies;
+    const int lsh = ilog2(copies);
+
+    const int dec_max = (bits == 3) ? 4 : 8;
+    int family = (M <= dec_max) ? 0 : 1;
+    if (g_ovr.family == 0 && M <= dec_max) family = 0;
+    if (g_ovr.family == 1) family = 1;
+    p->family = family;
+
+    if (family == 0) {
+        int mb = 1; while (mb < M) mb <<= 1;
+        if (g_ovr.m_block > 0 && g_ovr.m_block >= M && g_ovr.m_block <= dec_max) mb = g_ovr.m_block;
+        int waves = t.threads / 64;
+        if (g_ovr.waves > 0) waves = g_ovr.waves;
+        if (waves > 8) waves = 8;
+        const int kc = dec_kc(mb);
+        const int kw_max = kc / 512;              // every octet of a wave keeps >= 1 line per chunk
+        // total K split so that the chip sees >= num_sms*mult workgroups worth of waves
+        const long target_waves = (long)num_sms * t.sms_multiple * waves;
+        int f = 1;
+        while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
+        int kw = f < waves ? f : waves;
+        if (kw > kw_max) kw = kw_max;
+        int splitk = f / kw;
+        if (g_ovr.kw > 0) kw = g_ovr.kw;
+        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
+        while (waves % kw) kw >>= 1;
+        while ((units % (waves / kw)) && kw < waves) kw <<= 1;
+        int kps = round_up(ceil_div(K, splitk), 512);
+        splitk = ceil_div(K, kps);
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+            splitk >>= 1;
+            kps = round_up(ceil_div(K, splitk), 512);
+            splitk = ceil_div(K, kps);
+        }
+        if (splitk == 1) kps = K;
+        p->m_block = mb; p->waves = waves; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
+        p->grid = (unsigned)((units / (waves / kw)) * splitk);
+        p->block = (unsigned)(waves * 64);
+        p->lds_bytes = decode_lds_bytes(bits, mb, lg, waves, kw, kps, lsh);
+    } else {
+        int mt = t.tile_m / 16;
+        if (g_ovr.m_block > 0) mt = g_ovr.m_block;
+        const int mt_max = (bits == 3) ? 2 : 4;
+        if (mt > mt_max) mt = mt_max;
+        int need = 1; while (need * 16 < M && need < mt) need <<= 1;
+        mt = need;                                    // no wider than M asks for
+        if (mt != 1 && mt != 2 && mt != 4) mt = 1;
+        const int kc = (mt >= 4) ? 128 : 256;
+        const int slabs = units / 16;
+        const int mtiles = ceil_div(M, mt * 16);
+        int nw = 4;
+        while (nw > 1 && (slabs % nw)) nw >>= 1;
+        while (nw > 1 && (slabs / nw) * mtiles < num_sms) nw >>= 1;
+        if (g_ovr.waves > 0 && slabs % g_ovr.waves == 0 && g_ovr.waves <= 4) nw = g_ovr.waves;
+        const long wgs = (long)(slabs / nw) * mtiles;
+        int splitk = 1;
+        while (wgs * splitk * 2 <= (long)num_sms * t.sms_multiple && K / (splitk * 2) >= 512)
+            splitk *= 2;
+        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
+        int kps = round_up(ceil_div(K, splitk), kc);
+        splitk = ceil_div(K, kps);
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+            splitk >>= 1;
+            kps = round_up(ceil_div(K, splitk), kc);
+            splitk = ceil_div(K, kps);
+        }
+        if (splitk == 1) kps = K;
+        p->m_block = mt; p->waves = nw; p->kw = 1; p->splitk = splitk; p->k_per_split = kps;
+        p->grid = (unsigned)(wgs * splitk);
+        p->block = (unsigned)(nw * 64);
+        p->lds_bytes = mfma_lds_bytes(bits, mt, lg, nw, lsh);
+    }
+    p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
+    if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
+    return FLUTE_OK;
+}
+
+QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk) {
+    if (family == 0) {
+        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk);
+        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk);
+        return decode_kernel_b2(dtype, tile_p, mblk);
+    }
+    if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
+    if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);
+    return mfma_kernel_b2(dtype, tile_p, mblk);
+}
+
+// kernels that were already granted > 64 KB of dynamic LDS
+const void* g_big_lds[64];
+int g_big_lds_n = 0;
+
+int ensure_lds(const void* fn, size_t bytes) {
+    if (bytes <= 65536) return 0;
+    for (int i = 0; i < g_big_lds_n; ++i) if (g_big_lds[i] == fn) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+        (void)hipGetLastError();
+        return FLUTE_ERR_LAUNCH;
+    }
+    if (g_big_lds_n < 64) g_big_lds[g_big_lds_n++] = fn;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flute_abi_version(void) { return FLUTE_AMD_ABI_VERSION; }
+
+const char* flute_strerror(int status) {
+    switch (status) {
+        case FLUTE_OK: return "ok";
+        case FLUTE_ERR_NUM_BITS: return "Unsupported num_bits value";
+        case FLUTE_ERR_GROUP_SIZE: return "Unsupported group_size value";
+        case FLUTE_ERR_TEMPLATE_ID: return "Unsupported template_id value";
+        case FLUTE_ERR_SHAPE: return "Unsupported shape: need N % (16/num_bits*TileP) == 0 (N % 512 for 3 bits), K % 64 == 0, K % group_size == 0";
+        case FLUTE_ERR_WORKSPACE: return "workspace too small";
+        case FLUTE_ERR_LAUNCH: return "HIP error: kernel launch failed (invalid argument)";
+        case FLUTE_ERR_DTYPE: return "Unsupported dtype (fp16 / bf16 only)";
+        case FLUTE_ERR_HADAMARD_SIZE: return "Only power of two Hadamard sizes up to 2^15 are supported";
+        case FLUTE_ERR_NULL: return "null pointer argument";
+        default: return "unknown flute_amd status";
+    }
+}
+
+void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies) {
+    g_ovr = Overrides{family, m_block, waves, kw, splitk, lut_copies};
+}
+
+int flute_num_templates(int num_bits) {
+    if (num_bits == 4) return 144;
+    if (num_bits == 2 || num_bits == 3) return 36;
+    return 0;
+}
+
+int flute_get_template_info(int num_bits, int template_id, flute_template_info* out) {
+    if (!out) return FLUTE_ERR_NULL;
+    if (num_bits != 2 && num_bits != 3 && num_bits != 4) return FLUTE_ERR_NUM_BITS;
+    return decode_template(num_bits, template_id, out) ? FLUTE_OK : FLUTE_ERR_TEMPLATE_ID;
+}
+
+int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
+                     int template_id, int num_sms, size_t workspace_bytes, flute_plan* out) {
+    if (!out) return FLUTE_ERR_NULL;
+    return make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
+                     out, nullptr);
+}
+
+int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, int P,
+                const void* A, const void* Q, void* D, const void* S, const void* QM,
+                const void* QM2, void* workspace, size_t workspace_bytes, int template_id,
+                int num_sms, void* stream) {
+    (void)QM;   // single-code table: unused, the kernel reads only the pair table (as the reference)
+    if (M == 0) return FLUTE_OK;
+    flute_plan p;
+    flute_template_info t;
+    if (!workspace) workspace_bytes = 0;
+    const int rc = make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms,
+                             workspace_bytes, &p, &t);
+    if (rc) return rc;
+    if (P != num_bits * (N / 16)) return FLUTE_ERR_SHAPE;
+    if (!A || !Q || !D || !S || !QM2) return FLUTE_ERR_NULL;
+
+    QGemmArgs a;
+    a.A = A; a.Q = reinterpret_cast<const uint32_t*>(Q); a.D = D; a.S = S;
+    a.QM2 = reinterpret_cast<const uint32_t*>(QM2);
+    a.partial = reinterpret_cast<float*>(workspace);
+    a.M = M; a.N = N; a.K = K; a.G = K / group_size;
+    a.lg = ilog2(group_size);
+    a.units = N / ((num_bits == 3) ? 16 : 16 / num_bits);
+    a.splitk = p.splitk; a.k_per_split = p.k_per_split; a.kw = p.kw; a.m0 = 0;
+    a.lut_shift = ilog2(p.lut_copies);
+
+    QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block);
+    if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+    if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* kargs[] = {&a};
+    if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs,
+                        p.lds_bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return FLUTE_ERR_LAUNCH;
+    }
+    if (p.splitk > 1)
+        return splitk_reduce_dispatch(dtype, a.partial, D, (size_t)M * N, p.splitk, st);
+    return FLUTE_OK;
+}
+
+int flute_hadamard(int dtype, const void* in, void* out, uint32_t numel, uint32_t had_size,
+                   void* stream) {
+    if (!in || !out) return numel == 0 ? FLUTE_OK : FLUTE_ERR_NULL;
+    return hadamard_dispatch(dtype, in, out, numel, had_size, reinterpret_cast<hipStream_t>(stream));
+}
+
+int flute_unpack(int num_bits, int template_id, int N, int K, const void* Q, void* W,
+                 void* stream) {
+    flute_template_info t;
+    if (num_bits != 2 && num_bits != 3 && num_bits != 4) return FLUTE_ERR_NUM_BITS;
+    if (!decode_template(num_bits, template_id, &t)) return FLUTE_ERR_TEMPLATE_ID;
+    if (num_bits == 3 && t.tile_p != 32) return FLUTE_ERR_TEMPLATE_ID;
+    const int J = (num_bits == 3) ? 16 : 16 / num_bits;
+    if (N < 1 || K < 2 || N % (J * t.tile_p) || K % 2) return FLUTE_ERR_SHAPE;
+    if (!Q || !W) return FLUTE_ERR_NULL;
+    return unpack_dispatch(num_bits, t.tile_p, N, K, Q, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

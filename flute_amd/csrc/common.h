@@ -1,0 +1,147 @@
+// Shared device-side definitions for the gfx950 qgemm kernels.
+//
+// Packed weight format (the reference's wire format, kept bit-for-bit so that
+// weights packed by flute/utils.py:59-253 run unchanged).  View Q[P,K] int16
+// as Q32[P,K/2] uint32 (k = 2*kappa, 2*kappa+1 little endian):
+//   b in {4,2}, J = 16/b, row p = nb*TileP + t:
+//       field j (bits [2b*j, 2b*j+2b)) is column n = nb*J*TileP + j*TileP + t,
+//       high b bits = code of W[2kappa, n], low b bits = W[2kappa+1, n]
+//   b = 3 (TileP = 32), P1 = N/16, unit (nb, t):
+//       w0 = Q32[nb*32+t], w1 = Q32[P1+nb*64+t], w2 = Q32[P1+nb*64+32+t]
+//       j < 15: 6-bit field (w[j%3] >> 6*(j/3)) & 63;  j == 15: the three
+//       2-bit tops of w0,w1,w2 (low to high); n = nb*512 + j*32 + t
+// (reader in the reference: flute/csrc/packbits_utils.hpp:92-140, 322-362).
+//
+// A "unit" is the set of Q32 rows that decode together: one row for b=2/4,
+// the (w0,w1,w2) triple for b=3.  One unit covers J columns (4 / 8 / 16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flute_amd {
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct F16 {};   // dtype id 0
+struct BF16 {};  // dtype id 1
+
+// ---- arithmetic contract (packbits_utils.hpp:139, :344-361) ---------------
+//   w^ = round_T(table2[field] * scale)   one rounding, in T, both halves
+//   acc (fp32) += x * w^                  (config.hpp:323-325, kMixed)
+
+template <typename T> struct Num;
+
+template <> struct Num<F16> {
+    // pair (uint32 holding two fp16) times a scalar fp16 (low 16 bits of s)
+    static __device__ __forceinline__ uint32_t mul_scale(uint32_t v, uint32_t s) {
+        h2_t a = __builtin_bit_cast(h2_t, v);
+        h2_t b = __builtin_bit_cast(h2_t, s);
+        h2_t bb = {b.x, b.x};
+        return __builtin_bit_cast(uint32_t, a * bb);           // v_pk_mul_f16 op_sel
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a),
+                                      __builtin_bit_cast(h2_t, b), c, false);
+    }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        _Float16 h = (_Float16)f;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t u) {
+        return (float)__builtin_bit_cast(_Float16, u);
+    }
+};
+
+template <> struct Num<BF16> {
+    static __device__ __forceinline__ uint32_t mul_scale(uint32_t v, uint32_t s) {
+        // bf16 x bf16 is exact in fp32; one RNE rounding back to bf16
+        float lo = __builtin_bit_cast(float, v << 16);
+        float hi = __builtin_bit_cast(float, v & 0xffff0000u);
+        float sf = __builtin_bit_cast(float, s << 16);
+        b2_t r = {(__bf16)(lo * sf), (__bf16)(hi * sf)};        // v_cvt_pk_bf16_f32
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a),
+                                               __builtin_bit_cast(b2_t, b), c, false);
+    }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        __bf16 h = (__bf16)f;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t u) {
+        return __builtin_bit_cast(float, (uint32_t)u << 16);
+    }
+};
+
+// ---- layout traits ---------------------------------------------------------
+
+template <int BITS> struct Layout {
+    static constexpr int J = (BITS == 3) ? 16 : 16 / BITS;   // columns per unit
+    static constexpr int NPLANES = (BITS == 3) ? 3 : 1;       // Q32 rows per unit
+    static constexpr int FIELD_BITS = 2 * BITS;
+    static constexpr int LUT_N = 1 << FIELD_BITS;              // pair-table entries
+};
+
+// first column of unit u (columns are n0 + j*TILEP)
+template <int BITS, int TILEP>
+__device__ __forceinline__ int unit_col0(int u) {
+    constexpr int J = Layout<BITS>::J;
+    return (u / TILEP) * (J * TILEP) + (u % TILEP);
+}
+
+// Q32 row of plane `pl` of unit u
+template <int BITS, int TILEP>
+__device__ __forceinline__ int unit_row(int u, int pl, int N) {
+    if constexpr (BITS != 3) {
+        return u;
+    } else {
+        if (pl == 0) return u;
+        const int P1 = N >> 4;
+        return P1 + (u >> 5) * 64 + (pl - 1) * 32 + (u & 31);
+    }
+}
+
+// pair-table index of column j from the unit's words (same kappa in each plane)
+template <int BITS>
+__device__ __forceinline__ uint32_t field(const uint32_t (&w)[Layout<BITS>::NPLANES], int j) {
+    if constexpr (BITS == 4) {
+        return (w[0] >> (8 * j)) & 0xffu;
+    } else if constexpr (BITS == 2) {
+        return (w[0] >> (4 * j)) & 0xfu;
+    } else {
+        if (j < 15) return (w[j % 3] >> (6 * (j / 3))) & 63u;
+        return (w[0] >> 30) | ((w[1] >> 28) & 0xcu) | ((w[2] >> 26) & 0x30u);
+    }
+}
+
+// ---- kernel arguments --------------------------------------------------------
+
+struct QGemmArgs {
+    const void* A;          // [M,K]   T
+    const uint32_t* Q;      // [P,K/2] packed
+    void* D;                // [M,N]   T
+    const void* S;          // [N,G]   T
+    const uint32_t* QM2;    // [4^b]   pair table (two T per word)
+    float* partial;         // [splitk][M][N] fp32 when splitk > 1
+    int M, N, K, G;
+    int lg;                 // log2(group_size)
+    int units;              // N / J
+    int splitk;             // grid split of K
+    int k_per_split;        // multiple of 64
+    int kw;                 // waves of one workgroup that share a unit (split K inside the WG)
+    int m0;                 // first row of A/D this launch handles (M-blocking of the decode kernel)
+    int lut_shift;          // log2(LDS replicas of the pair table): 5, 4, 3 or 0
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace flute_amd

@@ -1,0 +1,101 @@
+"""`FluteLinear` - the drop-in quantized linear layer (flute/integrations/base.py:203-326).
+
+Same constructor, buffers (`weight[P,K] int16`, `scales[N,G]`, `tables[2^b]`,
+`tables2`), extra-state and forward semantics (in-place bias add) as the
+reference.  The model-walking quantizer / CLI of base.py:44-200,329-388 is
+outside the hot path.
+"""
+from typing import Dict, Optional
+
+import torch
+
+import flute_amd
+import flute_amd.utils
+
+
+class FluteLinear(torch.nn.Module):
+    __constants__ = ["in_features", "out_features", "num_bits", "group_size", "template_id",
+                     "num_sms", "workspace_lazy_init"]
+
+    def __init__(self, in_features: int, out_features: int, num_bits: int, group_size: int,
+                 template_id: int, workspace_lazy_init: bool = False, bias: bool = False,
+                 device: Optional[torch.device] = None, dtype: Optional[torch.dtype] = None) -> None:
+        if dtype not in [torch.float16, torch.bfloat16]:
+            raise NotImplementedError
+        if not isinstance(device, torch.device):
+            raise NotImplementedError
+        super().__init__()
+        K, N = in_features, out_features
+        P = int(N / 16 * num_bits)
+        G = int(K / group_size)
+        tables = torch.arange(2 ** num_bits, dtype=dtype, device=device)
+        if workspace_lazy_init:
+            num_sms, workspace = None, None
+        else:
+            num_sms = flute_amd.utils.get_device_num_sms(device)
+            workspace = flute_amd.utils.get_workspace_streamk(device)
+        self.in_features = in_features
+        self.out_features = out_features
+        self.num_bits = num_bits
+        self.group_size = group_size
+        self.template_id = template_id
+        self.num_sms = num_sms
+        self.workspace = workspace
+        self.workspace_lazy_init = workspace_lazy_init
+        self.register_buffer("weight", torch.empty((P, K), dtype=torch.int16, device=device))
+        self.register_buffer("scales", torch.ones((N, G), dtype=dtype, device=device))
+        self.register_buffer("tables", tables)
+        self.register_buffer("tables2", flute_amd.utils.make_qmap2_from_qmap(tables))
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_features, device=device, dtype=dtype))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        if self.workspace_lazy_init:
+            num_sms = flute_amd.utils.get_device_num_sms(inputs.device)
+            workspace = flute_amd.utils.get_workspace_streamk(inputs.device)
+        else:
+            num_sms, workspace = self.num_sms, self.workspace
+        output = flute_amd.qgemm(inputs, self.weight, self.scales, self.tables, self.tables2,
+                                 workspace, self.num_bits, self.group_size, self.template_id,
+                                 num_sms)
+        if self.bias is not None:
+            output.add_(self.bias)   # in place, base.py:298-299
+        return output
+
+    def extra_repr(self) -> str:
+        return (f"in_features={self.in_features}, out_features={self.out_features}, "
+                f"bias={self.bias is not None}, num_bits={self.num_bits}, "
+                f"group_size={self.group_size}")
+
+    def get_extra_state(self) -> Dict:
+        return {"num_bits": self.num_bits, "group_size": self.group_size,
+                "template_id": self.template_id}
+
+    def set_extra_state(self, state: Dict) -> None:
+        if self.num_bits != state["num_bits"] or self.group_size != state["group_size"]:
+            raise ValueError
+        if self.template_id is None:
+            self.template_id = state["template_id"]
+        if self.template_id != state["template_id"]:
+            raise ValueError
+
+    @classmethod
+    def from_codes(cls, codes: torch.Tensor, scales: torch.Tensor, tables: torch.Tensor,
+                   num_bits: int, group_size: int, template_id: int,
+                   bias: Optional[torch.Tensor] = None) -> "FluteLinear":
+        """Build a layer from integer codes [K, N], scales [N, G] and a table."""
+        K, N = codes.shape
+        layer = cls(K, N, num_bits, group_size, template_id, bias=bias is not None,
+                    device=scales.device, dtype=scales.dtype)
+        num_sms = flute_amd.utils.get_device_num_sms(scales.device)
+        layer.weight.copy_(flute_amd.utils.pack(codes.to(scales.device), num_bits,
+                                                [template_id], num_sms))
+        layer.scales.copy_(scales)
+        layer.tables.copy_(tables)
+        layer.tables2.copy_(flute_amd.utils.make_qmap2_from_qmap(tables.to(scales.dtype)))
+        if bias is not None:
+            with torch.no_grad():
+                layer.bias.copy_(bias)
+        return layer

@@ -1,0 +1,120 @@
+/* flute_amd C ABI - the drop-in boundary of the MI355X (gfx950) qgemm path.
+ *
+ * Plain pointers and sizes only (no torch types).  Every entry point is what a
+ * binding for the reference's hot path would call; the reference interface it
+ * replaces is cited on each declaration (paths relative to HanGuo97/flute
+ * v0.4.2).  All functions return 0 on success or a negative flute_status;
+ * flute_strerror() maps a status to the message prefix the reference raises
+ * (the reference's tuner string-matches those, flute/tune.py:160-167).
+ *
+ * Device pointers must be valid on the current HIP device, contiguous and 16-B
+ * aligned (torch allocations are).  Nothing here allocates, synchronises or
+ * touches the host after enqueue: every call is stream-ordered on `stream`
+ * (a hipStream_t) and hipGraph-capturable, like the reference's launch on
+ * at::cuda::getCurrentCUDAStream() (flute/csrc/qgemm.cpp:101-105).
+ */
+#ifndef FLUTE_AMD_H
+#define FLUTE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUTE_AMD_ABI_VERSION 1
+
+enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
+
+enum flute_status {
+    FLUTE_OK = 0,
+    FLUTE_ERR_NUM_BITS = -1,      /* "Unsupported num_bits value"    qgemm.cpp:171 */
+    FLUTE_ERR_GROUP_SIZE = -2,    /* "Unsupported group_size value"  qgemm.cpp:153 */
+    FLUTE_ERR_TEMPLATE_ID = -3,   /* "Unsupported template_id value" qgemm_kernel_raw_generated.cu:205 */
+    FLUTE_ERR_SHAPE = -4,         /* shape / divisibility precondition (ops.py:40-49) */
+    FLUTE_ERR_WORKSPACE = -5,     /* split-K needs more workspace than given */
+    FLUTE_ERR_LAUNCH = -6,        /* HIP launch failed ("CUDA error: invalid argument" analogue) */
+    FLUTE_ERR_DTYPE = -7,
+    FLUTE_ERR_HADAMARD_SIZE = -8, /* hadamard_transform.cpp:23-25 */
+    FLUTE_ERR_NULL = -9
+};
+
+/* One row of the gfx950 template table.  Same fields as the reference's
+ * TEMPLATE_CONFIGS entries (flute/codegen_utils.py:110-152,
+ * data/qgemm_kernel_raw_generated_configs.pth) and the same id -> TileP map, so
+ * weights packed by the reference for template id X decode correctly here under
+ * the same id.  Meaning of the knobs on gfx950:
+ *   sms_multiple  target workgroups per CU used to size the K split
+ *   threads       workgroup size of the decode kernel (MFMA kernel uses <= 256)
+ *   tile_m        rows per wave of the MFMA kernel (16/32/64)
+ *   tile_k        64 (granularity of K)
+ *   tile_p        packed-layout parameter (32/64) - fixes the wire format
+ *   stages        weight prefetch depth (k-steps / load batches)
+ *   lut_copies    LDS replicas of the pair table (QuantMapMode: 1/32/16/8) */
+typedef struct flute_template_info {
+    int num_bits, template_id;
+    int sms_multiple, threads, tile_m, tile_k, tile_p, stages, lut_copies;
+} flute_template_info;
+
+/* Launch plan chosen for a problem (host logic only, no GPU needed). */
+typedef struct flute_plan {
+    int family;          /* 0 = decode (streaming GEMV, M<=8), 1 = MFMA */
+    int m_block;         /* decode: rows per pass (1/2/4/8); MFMA: 16-row tiles per wave */
+    int waves;           /* waves per workgroup */
+    int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
+    int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */
+    int k_per_split;
+    int lut_copies;
+    unsigned grid, block;
+    size_t lds_bytes;
+    size_t workspace_needed;
+} flute_plan;
+
+/* D[M,N] = A[M,K] @ (table2-lookup(Q) * S)   fused LUT-dequant GEMM.
+ * Replaces _qgemm_raw<T,TQ,T2,NumBits,GroupSize>  (flute/csrc/qgemm.cpp:15-36,
+ * body flute/csrc/qgemm_kernel_raw_generated.cu:15-768 -> qgemm_host,
+ * qgemm_kernel.hpp:824-939).
+ *   A  [M,K] T row-major          Q  [P,K] int16, P = num_bits*N/16 (flute/utils.py:59-253)
+ *   S  [N,K/group_size] T         QM [2^b] T (unused by the kernel, as in the reference)
+ *   QM2 [2^b,2^b] pairs of T in one 32-bit word (flute/utils.py:15-33)
+ *   workspace: caller-owned scratch, used for split-K slabs; may be NULL when
+ *   the plan has splitk == 1 (flute/utils.py:36-56 over-allocates it). */
+int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, int P,
+                const void* A, const void* Q, void* D, const void* S, const void* QM,
+                const void* QM2, void* workspace, size_t workspace_bytes, int template_id,
+                int num_sms, void* stream);
+
+/* The plan flute_qgemm would use (exposed for tests and the offline tuner). */
+int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
+                     int template_id, int num_sms, size_t workspace_bytes, flute_plan* out);
+
+/* out = in.reshape(-1, had_size) @ (H/sqrt(had_size)), Sylvester order.
+ * Replaces run_fht<dtype>(a, out, numel, had_size, stream)
+ * (flute/csrc/hadamard_transform_cuda.cu:701-748; wrapper hadamard_transform.cpp:17-56;
+ * used by apply_hadamard, qgemm.cpp:201-211).  in == out is allowed. */
+int flute_hadamard(int dtype, const void* in, void* out, uint32_t numel, uint32_t had_size,
+                   void* stream);
+
+/* Q[P,K] -> integer codes W[K,N] uint8 on the device.  Native replacement for
+ * flute.utils.unpack, which runs qgemm on an identity matrix
+ * (flute/utils.py:347-407). */
+int flute_unpack(int num_bits, int template_id, int N, int K, const void* Q, void* W,
+                 void* stream);
+
+/* Template table (replaces data/qgemm_kernel_raw_generated_configs.pth +
+ * the generated switch, qgemm_kernel_raw_generated.cu:92-767). */
+int flute_num_templates(int num_bits);
+int flute_get_template_info(int num_bits, int template_id, flute_template_info* out);
+
+/* Tuning overrides for the offline tuner / benchmarks; -1 = automatic.
+ * family: 0 decode, 1 MFMA.  Process-global, not thread-safe. */
+void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies);
+
+const char* flute_strerror(int status);
+int flute_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUTE_AMD_H */

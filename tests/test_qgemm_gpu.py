@@ -1,0 +1,387 @@
+"""GPU parity tests: the HIP path (through torch.ops.flute.* -> C ABI) against the
+CPU oracle, the committed golden fixtures, and size-independent properties at
+BASELINE.json's full shapes.  Mirrors the reference's own tests
+(tests/kernel.py::test_integer, tests/higgs.py::test_vector_dequantize).
+
+Tolerances: rel-Frobenius < 1e-3 for fp16 (north_star) and < 8e-3 for bf16
+(one bf16 ulp is 2^-8; the reference accepts 1.1e-2, tests/kernel.py:13);
+identity input must reproduce round_T(table*scale) exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP16_TOL = 1e-3
+BF16_TOL = 8e-3
+
+
+def tol_of(dtype):
+    return FP16_TOL if dtype == torch.float16 else BF16_TOL
+
+
+@pytest.fixture(scope="module")
+def env():
+    import flute_amd
+    from flute_amd import utils
+    from oracle import flute_oracle as O
+    dev = torch.device("cuda:0")
+
+    class Env:
+        pass
+
+    e = Env()
+    e.fa, e.utils, e.O, e.dev = flute_amd, utils, O, dev
+    e.num_sms = utils.get_device_num_sms(dev)
+    e.ws = utils.get_workspace_streamk(dev)
+    return e
+
+
+def template_ids_for(fa, bits, tile_p, limit=None):
+    ids = [t for (b, t), c in sorted(fa.TEMPLATE_CONFIGS.items()) if b == bits and c["TileP"] == tile_p]
+    return ids if limit is None else ids[:limit]
+
+
+def run_qgemm(e, X, Q, S, table, table2, bits, g, tid):
+    d = e.dev
+    return e.fa.qgemm(X.to(d), torch.as_tensor(Q).to(d), S.to(d), table.to(d), table2.to(d),
+                      e.ws, bits, g, tid, e.num_sms).cpu()
+
+
+def rel_err(out, ref):
+    out, ref = out.float(), ref.float()
+    return ((out - ref).norm() / ref.norm()).item()
+
+
+# ---------------------------------------------------------------------------
+# golden fixtures (produced by the reference's own packers / formulas)
+# ---------------------------------------------------------------------------
+
+
+def test_golden_identity_exact(env, golden):
+    # tests/kernel.py:30-36,105-107 and tests/higgs.py:103-104
+    K = golden.Q.shape[1]
+    I = torch.eye(K, dtype=golden.dtype)
+    # one template per (SMs_Multiple, tile, lut mode) family with the fixture's TileP
+    tids = template_ids_for(env.fa, golden.num_bits, golden.tile_p)
+    for tid in tids[:: max(1, len(tids) // 6)]:
+        D = run_qgemm(env, I, golden.Q, golden.S, golden.table, golden.table2,
+                      golden.num_bits, golden.group_size, tid)
+        assert torch.equal(D, golden.D_identity), (golden.name, tid)
+
+
+def test_golden_random(env, golden):
+    if golden.kind != "kernel":
+        pytest.skip("HIGGS fixtures pin the identity case")
+    tid = template_ids_for(env.fa, golden.num_bits, golden.tile_p)[0]
+    D = run_qgemm(env, golden.A, golden.Q, golden.S, golden.table, golden.table2,
+                  golden.num_bits, golden.group_size, tid)
+    assert rel_err(D, golden.D) < tol_of(golden.dtype), golden.name
+
+
+# ---------------------------------------------------------------------------
+# seeded random vs the oracle (tests/kernel.py::test_integer distributions)
+# ---------------------------------------------------------------------------
+
+LAYOUTS = [(4, 32), (4, 64), (2, 32), (2, 64), (3, 32)]
+M_VALUES = [1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 53, 64, 100, 256]
+
+
+def make_case(e, bits, tile_p, g, dtype, K, N, seed, table_kind="randn"):
+    torch.manual_seed(seed)
+    W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8)
+    S = torch.randn(N, K // g).to(dtype)
+    if table_kind == "arange":
+        table = torch.arange(2 ** bits).to(dtype)
+    else:
+        table = torch.randn(2 ** bits).to(dtype)
+    table2 = e.utils.make_qmap2_from_qmap(table)
+    Q = torch.from_numpy(e.O.pack(W.numpy(), bits, tile_p))
+    return W, Q, S, table, table2
+
+
+@pytest.mark.parametrize("bits,tile_p", LAYOUTS)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_random_vs_oracle_all_M(env, bits, tile_p, dtype):
+    K, N, g = 1024, 1024, 64
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=bits * 10 + tile_p)
+    What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+    tids = template_ids_for(env.fa, bits, tile_p)
+    for i, M in enumerate(M_VALUES):
+        X = (torch.randn(M, K) / 100).to(dtype)
+        ref = (X.float() @ What).to(dtype)
+        tid = tids[(i * 7) % len(tids)]
+        D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+        assert D.shape == (M, N) and D.dtype == dtype
+        err = rel_err(D, ref)
+        assert err < tol_of(dtype), (bits, tile_p, dtype, M, tid, err)
+
+
+@pytest.mark.parametrize("bits,tile_p", LAYOUTS)
+@pytest.mark.parametrize("g", [32, 64, 128, 256])
+def test_group_sizes_identity_and_random(env, bits, tile_p, g):
+    dtype = torch.float16
+    K, N = 512, 512 if bits != 3 else 512
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=g + bits, table_kind="arange")
+    What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p)
+    tid = template_ids_for(env.fa, bits, tile_p)[1 % len(template_ids_for(env.fa, bits, tile_p))]
+    D = run_qgemm(env, torch.eye(K, dtype=dtype), Q, S, table, table2, bits, g, tid)
+    assert torch.equal(D, What), (bits, tile_p, g)
+    for M in (1, 4, 24):
+        X = (torch.randn(M, K) / 100).to(dtype)
+        D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+        assert rel_err(D, (X.float() @ What.float())) < FP16_TOL
+
+
+@pytest.mark.parametrize("bits,tile_p", LAYOUTS)
+def test_ragged_k_and_odd_shapes(env, bits, tile_p):
+    # K not a multiple of the 4096-k chunk / 512-k wave span; N = one or three blocks
+    dtype = torch.float16
+    blk = tile_p * (16 if bits == 3 else 16 // bits)
+    for K, N in ((64, blk), (192, blk), (4608, blk), (8256, 3 * blk)):
+        g = 64
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K + N)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        for M in (1, 3, 8, 20):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+            err = rel_err(D, X.float() @ What)
+            assert err < FP16_TOL, (bits, tile_p, K, N, M, err)
+
+
+def test_forced_splitk_and_kw_variants(env):
+    """Every K-split mode of both kernel families gives the same answer."""
+    bits, tile_p, g, dtype = 4, 32, 64, torch.float16
+    K, N = 4096, 512
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=7)
+    What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    lib = env.fa._lib.get()
+    try:
+        for M in (1, 4, 8, 16, 64):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ref = X.float() @ What
+            for kw in (1, 2, 4, 8):
+                for splitk in (1, 2, 4):
+                    for copies in (1, 8, 32):
+                        lib.flute_set_overrides(-1, -1, -1, kw, splitk, copies)
+                        D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+                        err = rel_err(D, ref)
+                        assert err < FP16_TOL, (M, kw, splitk, copies, err)
+    finally:
+        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+
+
+def test_mfma_family_for_small_M(env):
+    """Forcing the MFMA kernel at M <= 8 must agree with the decode kernel."""
+    bits, tile_p, g = 4, 64, 128
+    lib = env.fa._lib.get()
+    for dtype in (torch.float16, torch.bfloat16):
+        K, N = 1024, 512
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=3)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        try:
+            for M in (1, 7):
+                X = (torch.randn(M, K) / 100).to(dtype)
+                lib.flute_set_overrides(1, -1, -1, -1, -1, -1)
+                D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+                assert rel_err(D, X.float() @ What) < tol_of(dtype)
+        finally:
+            lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+
+
+# ---------------------------------------------------------------------------
+# full BASELINE shapes: size-independent properties, checker runs on the GPU
+# ---------------------------------------------------------------------------
+
+FULL_SHAPES = [
+    # (bits, tile_p, g, dtype, K, N)
+    (4, 32, 64, torch.float16, 4096, 4096),
+    (4, 64, 64, torch.float16, 4096, 11008),
+    (3, 32, 64, torch.bfloat16, 8192, 8192),
+    (4, 32, 64, torch.float16, 8192, 3584),      # TP=8 column shard of 8192x28672
+    (2, 64, 128, torch.bfloat16, 4096, 4096),
+]
+
+
+@pytest.mark.parametrize("bits,tile_p,g,dtype,K,N", FULL_SHAPES)
+def test_full_size_properties(env, bits, tile_p, g, dtype, K, N):
+    d = env.dev
+    torch.manual_seed(K + N + bits)
+    W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
+    S = torch.randn(N, K // g, device=d).to(dtype)
+    table = torch.randn(2 ** bits, device=d).to(dtype)
+    table2 = env.utils.make_qmap2_from_qmap(table)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    Q = env.utils.pack(W, bits, [tid], env.num_sms)
+    # host packer == oracle packer on a slice of rows
+    assert Q.shape == (bits * N // 16, K)
+    # ground truth weights on the GPU (tests/kernel.py:68-70), checker only
+    What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T      # [K, N] in T
+
+    def f(X, t=tid):
+        return env.fa.qgemm(X, Q, S, table, table2, env.ws, bits, g, t, env.num_sms)
+
+    # 1. one-hot rows select weight rows exactly (the identity test without a K x K input)
+    ks = torch.randint(0, K, (64,), device=d)
+    ks[0], ks[1] = 0, K - 1
+    X = torch.zeros(64, K, device=d, dtype=dtype)
+    X[torch.arange(64), ks] = 1
+    for M in (1, 4, 8, 64):
+        assert torch.equal(f(X[:M]), What[ks[:M]]), ("one-hot", M)
+    # 2. native unpack recovers the codes
+    assert torch.equal(env.utils.unpack_codes(Q, bits, tid), W)
+    # 3. random input vs torch.mm in fp32 on the GPU
+    for M in (1, 16, 256):
+        X = (torch.randn(M, K, device=d) / 100).to(dtype)
+        ref = X.float() @ What.float()
+        err = ((f(X).float() - ref).norm() / ref.norm()).item()
+        assert err < tol_of(dtype), (M, err)
+    # 4. linearity in X with exactly representable coefficients (2*x1 is exact in T)
+    x1 = (torch.randn(1, K, device=d) / 100).to(dtype)
+    assert torch.allclose(f(2 * x1).float(), 2 * f(x1).float(), rtol=2e-3, atol=1e-4)
+    # 5. row m of a batch does not depend on the other rows beyond accumulation order
+    Xb = (torch.randn(8, K, device=d) / 100).to(dtype)
+    yb = f(Xb).float()
+    y0 = f(Xb[:1]).float()
+    assert ((yb[:1] - y0).norm() / y0.norm()).item() < tol_of(dtype)
+
+
+# ---------------------------------------------------------------------------
+# HIGGS vector LUT (tests/higgs.py) and the Hadamard pre-rotation
+# ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("vector_size", [2, 1])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_higgs_vector_dequantize_exact(env, bits, vector_size, dtype):
+    from flute_amd.integrations import higgs
+    d = env.dev
+    torch.manual_seed(bits * 4 + vector_size)
+    N, K, g = 1024, 1024, 64
+    num_codes = 2 ** (bits * vector_size)
+    weight_higgs = torch.randint(0, num_codes, (N, K // vector_size), dtype=torch.uint8, device=d)
+    scales_higgs = torch.randn((N, K // g), device=d).to(dtype)
+    grid = torch.randn((num_codes, vector_size), device=d).to(dtype)
+    Q, S, tables, tables2, meta = higgs.prepare_data_transposed(
+        weight_higgs, scales_higgs, grid, bits, g, vector_size, dtype, d,
+        example_batch_size=1, check_correctness=(vector_size == 1))
+    I = torch.eye(K, dtype=dtype, device=d)
+    out = env.fa.qgemm(I, Q, S, tables, tables2, env.ws, bits, g, meta.template_id, meta.num_sms)
+    ref = env.O.vector_dequantize_higgs(weight_higgs.cpu(), scales_higgs.cpu(), grid.cpu())
+    assert torch.equal(out.cpu(), ref.T), (bits, vector_size, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("h", [2, 4, 8, 64, 256, 512, 1024, 4096, 8192, 16384, 32768])
+def test_hadamard_vs_definition(env, dtype, h):
+    # parity unpinned in the reference (no test there); oracle = H_h/sqrt(h) in fp64
+    torch.manual_seed(h)
+    rows = 3 if h >= 4096 else 37
+    x = torch.randn(rows, h).to(dtype)
+    y = env.fa.hadamard_transform(x.to(env.dev), h).cpu()
+    ref = env.O.hadamard_transform(x, h)
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2      # ~1 ulp of T rel. to the row norm
+    assert rel_err(y, ref) < tol, (h, rel_err(y, ref))
+    # several blocks per row
+    if h <= 512:
+        x2 = torch.randn(5, 4 * h).to(dtype)
+        y2 = env.fa.hadamard_transform(x2.to(env.dev), h).cpu()
+        assert rel_err(y2, env.O.hadamard_transform(x2, h)) < tol
+
+
+def test_qgemm_hadamard(env):
+    bits, tile_p, g, dtype, K, N, h = 4, 32, 64, torch.float16, 1024, 512, 512
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=11)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    d = env.dev
+    for M in (1, 5, 40):
+        X = (torch.randn(M, K) / 10).to(dtype)
+        ref = env.O.qgemm_hadamard(X, Q.numpy(), S, table, table2, bits, g, h, tile_p)
+        out = env.fa.qgemm_hadamard(X.to(d), Q.to(d), S.to(d), table.to(d), table2.to(d), env.ws,
+                                    bits, g, h, tid, env.num_sms).cpu()
+        assert rel_err(out, ref) < 3e-3, (M, rel_err(out, ref))
+
+
+# ---------------------------------------------------------------------------
+# boundary behaviour
+# ---------------------------------------------------------------------------
+
+
+def test_batch_dims_errors_and_graph(env):
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 512, 256
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=5)
+    d = env.dev
+    Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+    # leading batch dims are flattened and restored (qgemm.cpp:109-110,195-197)
+    X = (torch.randn(2, 3, K) / 100).to(dtype)
+    out = env.fa.qgemm(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms)
+    assert out.shape == (2, 3, N)
+    assert rel_err(out.cpu().reshape(6, N), X.reshape(6, K).float() @ What) < FP16_TOL
+    # keyword calling convention of qgemm_v2 (tune.py:508-531)
+    out2 = env.fa.qgemm(input=X.to(d), weight=Qd, scales=Sd, table=td, table2=t2d,
+                        workspace=env.ws, num_bits=bits, group_size=g, template_id=tid,
+                        num_sms=env.num_sms)
+    assert torch.equal(out, out2)
+    # error convention: RuntimeError with the reference's message prefixes
+    with pytest.raises(RuntimeError, match="Unsupported template_id value"):
+        env.fa.qgemm(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, 9999, env.num_sms)
+    with pytest.raises((RuntimeError, ValueError)):
+        env.fa.qgemm(X.to(d), Qd, Sd, td, t2d, env.ws, 5, g, tid, env.num_sms)
+    # no CPU fallback: CPU tensors have no kernel
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        env.fa.qgemm(X, Q, S, table, table2, torch.zeros(16, dtype=torch.uint8), bits, g, tid, 256)
+    # hipGraph capture and replay (qgemm.cpp:103-105: current stream, no host sync)
+    xg = X.to(d).reshape(6, K)[:1].contiguous()
+    static_out = env.fa.qgemm(xg, Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = env.fa.qgemm(xg, Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms)
+    xg.copy_((torch.randn(1, K) / 100).to(dtype))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert rel_err(static_out.cpu(), xg.cpu().float() @ What) < FP16_TOL
+
+
+def test_flute_linear_and_repack(env):
+    from flute_amd.integrations.base import FluteLinear
+    from flute_amd import tune
+    d = env.dev
+    bits, g, dtype, K, N = 4, 64, torch.float16, 1024, 512
+    torch.manual_seed(2)
+    codes = torch.randint(0, 16, (K, N), dtype=torch.uint8)
+    S = torch.randn(N, K // g).to(dtype).to(d)
+    table = torch.tensor(env.O.NF4_VALUES).to(dtype).to(d)
+    bias = torch.randn(N).to(dtype).to(d)
+    layer = FluteLinear.from_codes(codes, S, table, bits, g, template_id=0, bias=bias)
+    x = (torch.randn(3, K) / 10).to(dtype).to(d)
+    tile_p = env.fa.TEMPLATE_CONFIGS[(bits, 0)]["TileP"]
+    What = env.O.dequantize(layer.weight.cpu().numpy(), S.cpu(), layer.tables2.cpu(), bits, g, tile_p)
+    ref = x.cpu().float() @ What.float() + bias.cpu().float()
+    assert rel_err(layer(x).cpu(), ref) < 2e-3
+    sd = layer.state_dict()
+    assert set(k for k in sd if not k.startswith("_")) >= {"weight", "scales", "tables", "tables2", "bias"}
+    # a checkpoint "packed on another GPU" (num_sms 108, reference id 132, TileP 32)
+    ref_meta = tune.TuneMetaData(M=1, N=N, K=K, num_bits=bits, group_size=g, num_sms=108,
+                                 dtype=dtype, device=d, template_id=132)
+    Q_ref = torch.from_numpy(env.O.pack(codes.numpy(), bits, 32)).to(d)
+    Q_new, meta = tune.maybe_tune_and_repack(Q_ref, S, ref_meta, example_batch_size=1)
+    assert meta.num_sms == env.num_sms
+    assert torch.equal(env.utils.unpack_codes(Q_new, bits, meta.template_id).cpu(), codes)
+    assert tune.TuneMetaData.from_dict(meta.to_dict()) == meta
+
+
+def test_opcheck(env):
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 256, 128
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=1)
+    d = env.dev
+    args = (torch.eye(K, dtype=dtype, device=d), Q.to(d), S.to(d), table.to(d), table2.to(d),
+            env.ws, bits, g, template_ids_for(env.fa, bits, tile_p)[0], env.num_sms)
+    torch.library.opcheck(env.fa.qgemm, args)      # tune.py:350-360
