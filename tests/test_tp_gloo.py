@@ -1,0 +1,92 @@
+"""world_size-2 gloo test of the tensor-parallel sharding (CPU).  Per-rank compute
+is the oracle (injected through `qgemm_fn`); what is under test is that shards cut
+out of the packed matrix are valid packed matrices and that column-parallel
+(no collective) and row-parallel (one all-reduce) reproduce the unsharded result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_fn(tile_p):
+    from oracle import flute_oracle as O
+
+    def fn(x, Q, S, table, table2, bits, g, tid):
+        return O.qgemm(x, Q.numpy(), S, table, table2, bits, g, tile_p)
+    return fn
+
+
+def _worker(rank, world, port, bits, tile_p, g, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import flute_oracle as O
+        from flute_amd import tp
+        torch.manual_seed(0)
+        blk = tp.columns_per_block(bits, tile_p)
+        K, N, M, dtype = 512, 2 * world * blk, 3, torch.float32
+        # fp32 "T" keeps gloo reductions exact enough to compare tightly; the layout
+        # logic under test is dtype independent
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8)
+        Q = torch.from_numpy(O.pack(W.numpy(), bits, tile_p))
+        S16 = torch.randn(N, K // g).half()
+        table16 = torch.randn(2 ** bits).half()
+        table2 = O.make_qmap2_from_qmap(table16)
+        X = (torch.randn(M, K) / 10).half()
+        full = O.qgemm(X, Q.numpy(), S16, table16, table2, bits, g, tile_p).float()
+
+        fn = _oracle_fn(tile_p)
+        col = tp.ColumnParallelQLinear.from_full(Q, S16, table16, table2, bits, g, 0, tile_p,
+                                                 gather_output=True, qgemm_fn=fn)
+        # the shard is itself a valid packed matrix of the right shape
+        assert col.weight.shape == (bits * (N // world) // 16, K)
+        Wshard = O.unpack(col.weight.numpy(), bits, tile_p)
+        assert np.array_equal(Wshard, W.numpy()[:, rank * N // world:(rank + 1) * N // world])
+        y_col = col(X).float()
+        assert torch.equal(y_col, full), "column-parallel + all_gather"
+
+        row = tp.RowParallelQLinear.from_full(Q, S16, table16, table2, bits, g, 0,
+                                              qgemm_fn=lambda *a: fn(*a).float())
+        k0, k1 = rank * K // world, (rank + 1) * K // world
+        y_row = row(X[:, k0:k1].contiguous())
+        err = ((y_row - full).norm() / full.norm()).item()
+        assert err < 2e-3, err
+        result[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bits,tile_p", [(4, 32), (4, 64), (2, 32), (3, 32)])
+def test_tp_sharding_world2(bits, tile_p):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    result = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bits, tile_p, 64, result))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(result) == {0: 1, 1: 1}
+
+
+def test_shard_bounds_rejected():
+    from flute_amd import tp
+    Q = torch.zeros((4 * 128 // 16, 128), dtype=torch.int16)
+    S = torch.zeros((128, 2))
+    with pytest.raises(ValueError):
+        tp.shard_columns(Q, S, 4, 32, 2, 0)        # 128 columns = one block, cannot split
+    with pytest.raises(ValueError):
+        tp.shard_rows(Q, S, 64, 4, 0)              # 128 / 4 = 32 < 64
