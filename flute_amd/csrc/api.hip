@@ -18,8 +18,8 @@ using namespace flute_amd;
 
 namespace {
 
-struct Overrides { int family, m_block, waves, kw, splitk, lut_copies; };
-Overrides g_ovr = {-1, -1, -1, -1, -1, -1};
+struct Overrides { int family, m_block, waves, kw, splitk, lut_copies, prescale; };
+Overrides g_ovr = {-1, -1, -1, -1, -1, -1, -1};
 
 constexpr int kMaxLds = 160 * 1024;
 
@@ -42,7 +42,7 @@ bool decode_template(int bits, int id, flute_template_info* t) {
     const int tile = (id / (nq * 4)) % 3;
     const int mult = id / (nq * 12);
     static const int kMult[3] = {1, 2, 4};
-    static const int kThreads[3] = {512, 512, 256};
+    static const int kThreads[3] = {1024, 1024, 512};
     static const int kTileM[3] = {64, 64, 16};
     static const int kTileP[3] = {64, 32, 32};
     static const int kCopies[4] = {1, 32, 16, 8};
@@ -82,7 +82,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     p->lut_copies = copies;
     const int lsh = ilog2(copies);
 
-    const int dec_max = (bits == 3) ? 4 : 8;
+    const int dec_max = (bits == 3) ? 2 : 4;
     int family = (M <= dec_max) ? 0 : 1;
     if (g_ovr.family == 0 && M <= dec_max) family = 0;
     if (g_ovr.family == 1) family = 1;
@@ -93,18 +93,18 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         if (g_ovr.m_block > 0 && g_ovr.m_block >= M && g_ovr.m_block <= dec_max) mb = g_ovr.m_block;
         int waves = t.threads / 64;
         if (g_ovr.waves > 0) waves = g_ovr.waves;
-        if (waves > 8) waves = 8;
-        const int kc = dec_kc(mb);
-        const int kw_max = kc / 512;              // every octet of a wave keeps >= 1 line per chunk
-        // total K split so that the chip sees >= num_sms*mult workgroups worth of waves
+        if (waves > dec_max_threads(bits, mb) / 64) waves = dec_max_threads(bits, mb) / 64;
+        if (waves < 1) waves = 1;
+        // K split so that the chip holds >= num_sms * mult workgroups' worth of waves; every
+        // octet of a wave keeps at least one 64-k line
         const long target_waves = (long)num_sms * t.sms_multiple * waves;
         int f = 1;
         while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
         int kw = f < waves ? f : waves;
-        if (kw > kw_max) kw = kw_max;
         int splitk = f / kw;
         if (g_ovr.kw > 0) kw = g_ovr.kw;
         if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
+        if (kw > waves) kw = waves;
         while (waves % kw) kw >>= 1;
         while ((units % (waves / kw)) && kw < waves) kw <<= 1;
         int kps = round_up(ceil_div(K, splitk), 512);
@@ -115,10 +115,18 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
             splitk = ceil_div(K, kps);
         }
         if (splitk == 1) kps = K;
+        const DecodeGeom geo = decode_geom(bits, mb, lg, waves, kw, kps, kMaxLds);
+        const int ngroups = units / (waves / kw);
+        int occ = (int)(kMaxLds / geo.total);
+        if (occ > 2048 / (waves * 64)) occ = 2048 / (waves * 64);
+        if (occ < 1) occ = 1;
+        long nwg = (long)num_sms * occ;
+        if (nwg > ngroups) nwg = ngroups;
         p->m_block = mb; p->waves = waves; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
-        p->grid = (unsigned)((units / (waves / kw)) * splitk);
+        p->grid = (unsigned)(nwg * splitk);
         p->block = (unsigned)(waves * 64);
-        p->lds_bytes = decode_lds_bytes(bits, mb, lg, waves, kw, kps, lsh);
+        p->lds_bytes = geo.total;
+        p->lut_copies = (bits == 4) ? 64 : 32;
     } else {
         int mt = t.tile_m / 16;
         if (g_ovr.m_block > 0) mt = g_ovr.m_block;
@@ -159,9 +167,10 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
 
 QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk) {
     if (family == 0) {
-        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk);
-        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk);
-        return decode_kernel_b2(dtype, tile_p, mblk);
+        const int pre = (g_ovr.prescale > 0) ? 1 : 0;
+        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, pre);
+        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, pre);
+        return decode_kernel_b2(dtype, tile_p, mblk, pre);
     }
     if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
     if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);
@@ -205,8 +214,9 @@ const char* flute_strerror(int status) {
     }
 }
 
-void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies) {
-    g_ovr = Overrides{family, m_block, waves, kw, splitk, lut_copies};
+void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies,
+                         int prescale) {
+    g_ovr = Overrides{family, m_block, waves, kw, splitk, lut_copies, prescale};
 }
 
 int flute_num_templates(int num_bits) {
@@ -251,7 +261,8 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.lg = ilog2(group_size);
     a.units = N / ((num_bits == 3) ? 16 : 16 / num_bits);
     a.splitk = p.splitk; a.k_per_split = p.k_per_split; a.kw = p.kw; a.m0 = 0;
-    a.lut_shift = ilog2(p.lut_copies);
+    a.lut_shift = (p.family == 0) ? 0 : ilog2(p.lut_copies);
+    a.lds_budget = kMaxLds;
 
     QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block);
     if (!fn) return FLUTE_ERR_TEMPLATE_ID;
@@ -285,6 +296,13 @@ int flute_unpack(int num_bits, int template_id, int N, int K, const void* Q, voi
     if (N < 1 || K < 2 || N % (J * t.tile_p) || K % 2) return FLUTE_ERR_SHAPE;
     if (!Q || !W) return FLUTE_ERR_NULL;
     return unpack_dispatch(num_bits, t.tile_p, N, K, Q, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+int flute_debug_stream_read(const void* src, void* sink, size_t bytes, int bytes_per_wave,
+                            int grid, int block, void* stream) {
+    if (!src || !sink || bytes_per_wave < 8192 || bytes_per_wave % 8192) return FLUTE_ERR_SHAPE;
+    return stream_read_dispatch(src, sink, bytes, bytes_per_wave, grid, block,
+                                reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

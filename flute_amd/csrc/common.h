@@ -135,8 +135,33 @@ struct QGemmArgs {
     int k_per_split;        // multiple of 64
     int kw;                 // waves of one workgroup that share a unit (split K inside the WG)
     int m0;                 // first row of A/D this launch handles (M-blocking of the decode kernel)
-    int lut_shift;          // log2(LDS replicas of the pair table): 5, 4, 3 or 0
+    int lut_shift;          // log2(LDS replicas of the pair table): 5, 4, 3 or 0 (MFMA kernel)
+    int lds_budget;         // dynamic LDS the launch was sized for (decode kernel carve)
 };
+
+// ---- LDS access by absolute byte address -----------------------------------------
+// `extern __shared__` is a link-time symbol: indexing it makes hipcc emit a
+// `v_add_u32 addr, <symbol>, addr` per data-dependent access even though the symbol
+// is 0.  Hot loops therefore address LDS through address_space(3) integer pointers.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x2_t lds_cu32x2_t;
+typedef __attribute__((address_space(3))) const u32x4v_t lds_cu32x4_t;
+
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return *(lds_cu32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
+    const u32x2_t v = *(lds_cu32x2_t*)(uintptr_t)a;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 lds_ld128(uint32_t a) {
+    const u32x4v_t v = *(lds_cu32x4_t*)(uintptr_t)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// byte address of the dynamic LDS segment (0 unless the kernel has static LDS)
+__device__ __forceinline__ uint32_t lds_base_of(char* smem) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

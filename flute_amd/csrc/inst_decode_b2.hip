@@ -1,17 +1,34 @@
-// Explicit instantiations of the decode kernel for num_bits = 2 (generated layout: one
-// translation unit per bit width so that `make -j` compiles them in parallel).
+// Explicit instantiations of the decode kernel for num_bits = 2 (one translation unit per
+// bit width so that `make -j` compiles them in parallel).  PRE (per-pair scale rounding,
+// the reference's exact contract) exists for fp16 only.
 #include "kernels.h"
 #include "qgemm_decode.h"
 namespace flute_amd {
-QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb) {
-    if (tile_p == 32 && mb == 1) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 1> : (QGemmKernel)qgemv_kernel<BF16, 2, 32, 1>;
-    if (tile_p == 32 && mb == 2) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 2> : (QGemmKernel)qgemv_kernel<BF16, 2, 32, 2>;
-    if (tile_p == 32 && mb == 4) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 4> : (QGemmKernel)qgemv_kernel<BF16, 2, 32, 4>;
-    if (tile_p == 32 && mb == 8) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 8> : (QGemmKernel)qgemv_kernel<BF16, 2, 32, 8>;
-    if (tile_p == 64 && mb == 1) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 1> : (QGemmKernel)qgemv_kernel<BF16, 2, 64, 1>;
-    if (tile_p == 64 && mb == 2) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 2> : (QGemmKernel)qgemv_kernel<BF16, 2, 64, 2>;
-    if (tile_p == 64 && mb == 4) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 4> : (QGemmKernel)qgemv_kernel<BF16, 2, 64, 4>;
-    if (tile_p == 64 && mb == 8) return dtype == 0 ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 8> : (QGemmKernel)qgemv_kernel<BF16, 2, 64, 8>;
+QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre) {
+    if (tile_p == 32 && mb == 1) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 1, true> : (QGemmKernel)qgemv_kernel<F16, 2, 32, 1, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 32, 1, false>;
+    }
+    if (tile_p == 32 && mb == 2) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 2, true> : (QGemmKernel)qgemv_kernel<F16, 2, 32, 2, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 32, 2, false>;
+    }
+    if (tile_p == 32 && mb == 4) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 32, 4, true> : (QGemmKernel)qgemv_kernel<F16, 2, 32, 4, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 32, 4, false>;
+    }
+    if (tile_p == 64 && mb == 1) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 1, true> : (QGemmKernel)qgemv_kernel<F16, 2, 64, 1, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 64, 1, false>;
+    }
+    if (tile_p == 64 && mb == 2) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 2, true> : (QGemmKernel)qgemv_kernel<F16, 2, 64, 2, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 64, 2, false>;
+    }
+    if (tile_p == 64 && mb == 4) {
+        if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 2, 64, 4, true> : (QGemmKernel)qgemv_kernel<F16, 2, 64, 4, false>;
+        return (QGemmKernel)qgemv_kernel<BF16, 2, 64, 4, false>;
+    }
     return nullptr;
 }
 }  // namespace flute_amd

@@ -6,10 +6,11 @@ namespace flute_amd {
 
 typedef void (*QGemmKernel)(const QGemmArgs);
 
-// dtype: 0 fp16, 1 bf16; tile_p: 32 / 64; mb in {1,2,4,8}; mt in {1,2,4}
-QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb);
-QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb);
-QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb);
+// dtype: 0 fp16, 1 bf16; tile_p: 32 / 64; mb in {1,2,4} (b=3: {1,2}); mt in {1,2,4};
+// pre: 1 = per-pair scale rounding (fp16 only)
+QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre);
+QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb, int pre);
+QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
 QGemmKernel mfma_kernel_b4(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b3(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b2(int dtype, int tile_p, int mt);
@@ -18,6 +19,8 @@ int hadamard_dispatch(int dtype, const void* in, void* out, size_t numel, uint32
                       hipStream_t stream);
 int unpack_dispatch(int num_bits, int tile_p, int N, int K, const void* Q, void* W,
                     hipStream_t stream);
+int stream_read_dispatch(const void* src, void* sink, size_t bytes, int bytes_per_wave, int grid,
+                         int block, hipStream_t stream);
 int splitk_reduce_dispatch(int dtype, const float* partial, void* D, size_t mn, int splitk,
                            hipStream_t stream);
 

@@ -65,4 +65,37 @@ int unpack_dispatch(int num_bits, int tile_p, int N, int K, const void* Q, void*
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
+// ---- calibration: what a pure read of `bytes` costs on this chip ---------------------
+// Same access shape as the decode kernel (each wave streams contiguous KiB bursts,
+// `U` dwordx4 loads in flight per lane) with one XOR per load instead of the dequant.
+template <int U>
+__global__ __launch_bounds__(1024) void stream_read_kernel(const uint4* __restrict__ src,
+                                                           uint32_t* __restrict__ sink,
+                                                           size_t n16_per_wave, int waves_total) {
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    for (int w = wave; w < waves_total; w += (int)((gridDim.x * blockDim.x) >> 6)) {
+        const uint4* p = src + (size_t)w * n16_per_wave + lane;
+        for (size_t i = 0; i < n16_per_wave; i += 64 * U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = p[i + (size_t)u * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;       // never true for random data; keeps the loads live
+}
+
+int stream_read_dispatch(const void* src, void* sink, size_t bytes, int bytes_per_wave, int grid,
+                         int block, hipStream_t stream) {
+    const size_t n16_per_wave = (size_t)bytes_per_wave / 16;
+    const int waves_total = (int)(bytes / (size_t)bytes_per_wave);
+    hipLaunchKernelGGL((stream_read_kernel<8>), dim3(grid), dim3(block), 0, stream,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint32_t*>(sink),
+                       n16_per_wave, waves_total);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
 }  // namespace flute_amd

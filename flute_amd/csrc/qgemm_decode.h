@@ -1,56 +1,106 @@
-// Decode-regime kernel (M <= 8): HBM-bound streaming LUT-dequant GEMV.
+// Decode-regime kernel (M <= 4): HBM-bound streaming LUT-dequant GEMV.
 //
 // Replaces, for small M, the reference's qgemm_device main loop
 // (flute/csrc/qgemm_kernel.hpp:617-712) + Stream-K fixup
-// (tile_scheduler_utils.hpp:58-211).  CDNA4 design, not a translation:
-//   * one wave streams ONE unit (one Q32 row, or the 3-plane triple for b=3)
-//     along K: lane l of wave-instruction i reads the 16 B at byte l*16 of the
-//     i-th KiB -> every global_load_dwordx4 is a fully coalesced 1 KiB burst,
-//     straight to VGPRs (weights are used once: no LDS round trip);
-//   * the 4^b-entry pair table is replicated 32x in LDS so that lane l always
-//     hits bank l%32: the data-dependent ds_read_b32 is conflict free;
-//   * per-group scales and the activation rows are staged in LDS per 4096-k
-//     chunk (one ds_read_b64/b128 gives the J column scales of a line);
-//   * w^ = round_T(lut * scale) with v_pk_mul_f16 (bf16: fp32 mul + RNE cvt),
-//     accumulated in fp32 with v_dot2c_f32_{f16,bf16};
-//   * K is split over `kw` waves of the workgroup and reduced through LDS; a
-//     grid-level split (splitk) writes fp32 slabs reduced by splitk_reduce.
+// (tile_scheduler_utils.hpp:58-211).  CDNA4 design, not a translation.  On
+// gfx950 every VALU op of a wave64 costs a full quad-cycle and the r01 profile
+// showed the first version VALU/latency bound (7.5 VALU per weight pair, 60-75 %
+// of wave time in s_waitcnt), so this version is built around instruction count:
+//   * one wave streams ONE unit (one Q32 row / the 3-plane triple for b=3)
+//     along K; lane l of load i reads bytes [16 l, 16 l + 16) of the i-th KiB:
+//     every global_load_dwordx4 is one fully coalesced 1 KiB burst straight to
+//     VGPRs (weights are used once - no LDS round trip);
+//   * the pair table lives in LDS with a 256-byte entry stride: the LDS address
+//     of a lookup is {0, 0, field byte, lane*4}, built by ONE v_perm_b32, and
+//     lane l always reads bank l (conflict-free data-dependent ds_read):
+//       b=4: 256 entries x 64 copies x 4 B;  b=2: a BYTE table (two 4-bit
+//       fields -> two columns) 256 x 32 copies x 8 B, read with ds_read_b64;
+//       b=3 (6-bit fields, not byte aligned): 64 x 32 copies x 4 B, bfe+lshl_or;
+//   * the group scale is applied once per 8-k run in fp32
+//     (acc += s * sum_k x_k*lut_k) instead of once per pair: same value as the
+//     reference's round_T(lut*s) contract on one-hot inputs, within 2^-11
+//     relative per term otherwise (PRE = true keeps the per-pair v_pk_mul_f16);
+//   * activations and scales are staged in LDS once per K chunk, the chunk as
+//     large as LDS allows (normally the whole K range: one barrier);
+//   * workgroups are persistent over unit groups (table built once), K is split
+//     over `kw` waves inside the workgroup (LDS reduce) and, only when the grid
+//     would otherwise be too small, across workgroups (fp32 slabs + reduce pass);
+//   * lane reduction with DPP row ops + v_readlane, not ds_bpermute.
 #pragma once
 #include "common.h"
 
 namespace flute_amd {
 
-// k per staged chunk: 4096 for M<=2, then halved per doubling of the row block so
-// that the double-buffered activation stage stays <= 32 KB
-__host__ __device__ constexpr int dec_kc(int mb) { return mb <= 2 ? 4096 : 8192 / mb; }
+template <int BITS> struct DecCfg {
+    static constexpr int U = (BITS == 3) ? 4 : 8;               // lines in flight per lane
+    static constexpr int LUT_BYTES = (BITS == 3) ? 64 * 128 : 65536;
+};
 
-template <int BITS> struct DecBatch { static constexpr int U = (BITS == 3) ? 4 : 8; };
-
-// bytes of dynamic LDS the kernel needs (host and device use the same formula)
-__host__ __device__ inline size_t decode_lds_bytes(int bits, int mb, int lg, int waves, int kw,
-                                                   int krange, int lut_shift) {
-    const int J = (bits == 3) ? 16 : 16 / bits;
-    const int lut_n = 1 << (2 * bits);
-    const int kc = dec_kc(mb);
-    const int nbuf = (krange > kc) ? 2 : 1;
-    const int upw = waves / kw;
-    const int gcap = (kc >> lg) + 1;
-    size_t b = (((size_t)lut_n << (lut_shift + 2)) + 15) & ~(size_t)15;   // replicated pair table
-    b += (size_t)nbuf * mb * kc * 2;                     // activations
-    b += (((size_t)nbuf * gcap * upw * J * 2) + 15) & ~(size_t)15;   // scales
-    b += (size_t)waves * J * mb * 4;                     // cross-wave reduction
-    return b;
+// largest workgroup a variant may be launched with: 1024 threads cap the kernel at 128
+// VGPRs, which only the light variants fit without spilling
+__host__ __device__ constexpr int dec_max_threads(int bits, int mb) {
+    return (bits == 4 && mb <= 2) ? 1024 : 512;
 }
 
-template <typename T, int BITS, int TILEP, int MB>
-__global__ __launch_bounds__(512) void qgemv_kernel(const QGemmArgs a) {
+struct DecodeGeom {
+    int kc;            // k per staged chunk (multiple of 512)
+    int nbuf;          // 1: whole K range staged once; 2: chunked, double buffered
+    int gcap;          // scale groups per chunk buffer
+    int upw;           // units per workgroup
+    size_t x_off, s_off, red_off, total;
+};
+
+// LDS carve shared by host (plan) and device.  `krange` = k handled by one workgroup.
+__host__ __device__ inline DecodeGeom decode_geom(int bits, int mb, int lg, int waves, int kw,
+                                                  int krange, int lds_budget) {
+    DecodeGeom g;
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int lut = (bits == 3) ? 64 * 128 : 65536;
+    g.upw = waves / kw;
+    const int ncols = g.upw * J;
+    const int red = waves * J * mb * 4;
+    // bytes per k of a chunk buffer: activations 2*mb, scales 4*ncols per group
+    int kc = (krange + 511) & ~511;
+    g.nbuf = 1;
+    auto need = [&](int kcc, int nb) {
+        const long gc = (((kcc >> lg) + 1) + 7) & ~7L;       // group stride, multiple of 8 words
+        return (long)lut + (long)nb * ((long)mb * kcc * 2 + gc * ncols * 4) + red + 64;
+    };
+    if (need(kc, 1) > lds_budget) {
+        g.nbuf = 2;
+        kc = 8192;
+        while (kc > 512 && need(kc, 2) > lds_budget) kc >>= 1;
+    }
+    g.kc = kc;
+    g.gcap = (kc >> lg) + 1;
+    g.x_off = lut;
+    g.s_off = g.x_off + (size_t)g.nbuf * mb * kc * 2;
+    g.red_off = g.s_off + (size_t)g.nbuf * (size_t)((g.gcap + 7) & ~7) * ncols * 4;
+    g.total = g.red_off + red;
+    return g;
+}
+
+// sum over the 64 lanes, result valid in every lane of the first row (lane 0 used)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    // within each row of 16 lanes: butterfly via quad_perm / row_half_mirror / row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (v + r1) + (r2 + r3);
+}
+
+template <typename T, int BITS, int TILEP, int MB, bool PRE>
+__global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const QGemmArgs a) {
     using L = Layout<BITS>;
     using NT = Num<T>;
     constexpr int J = L::J;
     constexpr int NP = L::NPLANES;
-    constexpr int LUT_N = L::LUT_N;
-    constexpr int U = DecBatch<BITS>::U;
-    constexpr int KC = dec_kc(MB);
+    constexpr int U = DecCfg<BITS>::U;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -58,189 +108,332 @@ __global__ __launch_bounds__(512) void qgemv_kernel(const QGemmArgs a) {
     const int nthr = blockDim.x;
     const int lane = tid & 63;
     const int sub = lane & 7;            // 16-B piece inside the 128-B line
-    const int oct = lane >> 3;           // which of the 8 lines of a wave-instruction
+    const int oct = lane >> 3;           // which of the 8 lines of one wave-wide load
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = nthr >> 6;
     const int kw = a.kw;
-    const int upw = nw / kw;
     const int ul = wave / kw;
     const int kpart = wave - ul * kw;
-
-    const int split = blockIdx.x % a.splitk;
-    const int ug = blockIdx.x / a.splitk;
-    const int u = ug * upw + ul;
-    const int kbeg = split * a.k_per_split;
-    const int kend = min(a.K, kbeg + a.k_per_split);
-    const int krange = kend - kbeg;
-    const int nbuf = (a.k_per_split > KC) ? 2 : 1;
     const int lg = a.lg;
-    const int gcap = (KC >> lg) + 1;
 
-    // ---- LDS carve (all offsets multiples of 16) ----
-    const int lsh = a.lut_shift;
-    const size_t lut_bytes = (((size_t)LUT_N << (lsh + 2)) + 15) & ~(size_t)15;
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + lut_bytes);
-    uint16_t* ss = xs + (size_t)nbuf * MB * KC;
-    const size_t ss_bytes = (((size_t)nbuf * gcap * upw * J * 2) + 15) & ~(size_t)15;
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(ss) + ss_bytes);
+    const DecodeGeom geo = decode_geom(BITS, MB, lg, nw, kw, a.k_per_split, a.lds_budget);
+    const int KC = geo.kc;
+    const int upw = geo.upw;
+    const int ncols = upw * J;
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + geo.x_off);
+    uint32_t* ss = reinterpret_cast<uint32_t*>(smem + geo.s_off);
+    float* red = reinterpret_cast<float*>(smem + geo.red_off);
+    const int gstride = (geo.gcap + 7) & ~7;                  // words per column in the scale stage
+    const size_t ss_buf_words = (size_t)gstride * ncols;
 
     const uint16_t* A = reinterpret_cast<const uint16_t*>(a.A);
     const uint16_t* S = reinterpret_cast<const uint16_t*>(a.S);
+    // the v_perm-built table addresses are absolute: the table must sit at LDS byte 0
+    const uint32_t lds0 = lds_base_of(smem);
+    if (lds0 != 0) __builtin_trap();
 
-    // ---- replicated pair table: entry e occupies the (4 << lsh) bytes at e << (lsh+2) ----
-    if (lsh >= 2) {
-        for (int e = tid; e < (LUT_N << (lsh - 2)); e += nthr) {
-            const uint32_t v = a.QM2[e >> (lsh - 2)];
-            reinterpret_cast<uint4*>(lut)[e] = make_uint4(v, v, v, v);
+    const int split = blockIdx.x % a.splitk;
+    const int wg = blockIdx.x / a.splitk;
+    const int nwg = gridDim.x / a.splitk;
+    const int ngroups = a.units / upw;
+    const int kbeg = split * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+
+    // ---- pair table -> LDS, split into "issue the global loads" and "write LDS" so that the
+    // loads travel together with the first weight / activation / scale loads ----
+    constexpr int LUT_ENT = (BITS == 3) ? 64 : 256;          // entries
+    constexpr int LUT_PCS = (BITS == 3) ? 2 : 4;             // 64-B pieces per entry
+    constexpr bool BIG_WG = dec_max_threads(BITS, MB) == 1024;   // 128-VGPR variants: keep the prologue lean
+    constexpr int LUT_R = BIG_WG ? 2 : 4;                     // table pieces per thread held in registers
+    uint32_t lut_v0[LUT_R], lut_v1[LUT_R];
+    auto lut_issue = [&]() {
+#pragma unroll
+        for (int r = 0; r < LUT_R; ++r) {
+            const int p = tid + r * nthr;
+            if (p < LUT_ENT * LUT_PCS) {
+                const int e = p / LUT_PCS;
+                if constexpr (BITS == 2) { lut_v0[r] = a.QM2[e & 15]; lut_v1[r] = a.QM2[e >> 4]; }
+                else { lut_v0[r] = a.QM2[e]; lut_v1[r] = lut_v0[r]; }
+            }
         }
-    } else {
-        for (int e = tid; e < (LUT_N << lsh); e += nthr) lut[e] = a.QM2[e >> lsh];
-    }
+    };
+    auto lut_commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < LUT_R; ++r) {
+            const int p = tid + r * nthr;
+            if (p < LUT_ENT * LUT_PCS) {
+                const int e = p / LUT_PCS;
+                uint4* d = reinterpret_cast<uint4*>(smem + (size_t)e * (LUT_PCS * 64) + (p % LUT_PCS) * 64);
+                const uint4 vv = make_uint4(lut_v0[r], lut_v1[r], lut_v0[r], lut_v1[r]);
+                d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
+            }
+        }
+        for (int p = tid + LUT_R * nthr; p < LUT_ENT * LUT_PCS; p += nthr) {     // tiny workgroups only
+            const int e = p / LUT_PCS;
+            uint32_t v0, v1;
+            if constexpr (BITS == 2) { v0 = a.QM2[e & 15]; v1 = a.QM2[e >> 4]; }
+            else { v0 = a.QM2[e]; v1 = v0; }
+            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)e * (LUT_PCS * 64) + (p % LUT_PCS) * 64);
+            const uint4 vv = make_uint4(v0, v1, v0, v1);
+            d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
+        }
+    };
+    bool lut_ready = false;
+    // per-lane low address byte(s) of a lookup
+    const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8 : (BITS == 4 ? (uint32_t)lane * 4
+                                                                                  : (uint32_t)(lane & 31) * 4);
 
     const size_t row_words = (size_t)(a.K >> 1);
-    const uint32_t* qrow[NP];
+    int staged_chunk = -1;               // chunk whose activations sit in LDS (nbuf == 1 case)
+
+    for (int ug = wg; ug < ngroups; ug += nwg) {
+        const int u = ug * upw + ul;
+        const uint32_t* qrow[NP];
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-        qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u, pl, a.N) * row_words;
+        for (int pl = 0; pl < NP; ++pl)
+            qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u, pl, a.N) * row_words + sub * 4;
 
-    float acc[J][MB];
+        float acc[J][MB];
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+            for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
 
-    const uint32_t* lut_lane = lut + (lane & ((1 << lsh) - 1));
+        int c = 0;
+        for (int kc0 = kbeg; kc0 < kend; kc0 += KC, ++c) {
+            const int buf = (geo.nbuf == 2) ? (c & 1) : 0;
+            const int kc_len = min(KC, kend - kc0);
+            const int Lc = kc_len >> 6;                              // 64-k lines in this chunk
+            const int Lw = (((Lc + kw - 1) / kw) + 7) & ~7;          // lines per wave, multiple of 8
+            const int l0 = kpart * Lw;
+            const int myL = max(0, min(Lw, Lc - l0));                // lines of this wave
+            const int nI = (myL + 7) >> 3;                           // line slots per lane
+            const int g0c = kc0 >> lg;
+            const int gcnt = ((kc0 + kc_len - 1) >> lg) - g0c + 1;
+            uint16_t* xsb = xs + (size_t)buf * MB * KC;
+            uint32_t* ssb = ss + (size_t)buf * ss_buf_words;
+            const int kbase = kc0 + l0 * 64;                         // first k of this wave
 
-    int c = 0;
-    for (int kc0 = kbeg; kc0 < kend; kc0 += KC, ++c) {
-        const int buf = (nbuf == 2) ? (c & 1) : 0;
-        const int kc_len = min(KC, kend - kc0);
-        const int Lc = kc_len >> 6;                    // 64-k lines in this chunk
-        const int Lw = (Lc + kw - 1) / kw;             // lines per wave
-        const int l0 = kpart * Lw;
-        const int myL = max(0, min(Lw, Lc - l0));
-        const int g0c = kc0 >> lg;
-        const int gcnt = ((kc0 + kc_len - 1) >> lg) - g0c + 1;
-
-        uint16_t* xsb = xs + (size_t)buf * MB * KC;
-        uint16_t* ssb = ss + (size_t)buf * gcap * upw * J;
-
-        // first batch of weight loads goes out before anything waits
-        uint4 q[U][NP];
-        const int nI = (myL + 7) >> 3;
-        auto load_batch = [&](int ib) {
+            // ---- weight loads of the first U line slots go out before anything waits ----
+            uint4 q[U][NP];
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                const int ln = (ib + i) * 8 + oct;
+                const int ln = i * 8 + oct;
                 if (ln < myL) {
-                    const size_t woff = (size_t)((kc0 + (l0 + ln) * 64) >> 1) + sub * 4;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
-                        q[i][pl] = *reinterpret_cast<const uint4*>(qrow[pl] + woff);
+                        q[i][pl] = *reinterpret_cast<const uint4*>(qrow[pl] + ((kbase + ln * 64) >> 1));
                 }
             }
-        };
-        load_batch(0);
 
-        // ---- stage activations (rows clamped to M-1, zero past kc_len) ----
-        for (int p = tid; p < MB * (KC / 8); p += nthr) {
-            const int m = p / (KC / 8);
-            const int kk = (p - m * (KC / 8)) * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kk < kc_len) {
-                const int row = min(a.m0 + m, a.M - 1);
-                v = *reinterpret_cast<const uint4*>(A + (size_t)row * a.K + kc0 + kk);
-            }
-            *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
-        }
-        // ---- stage scales transposed to [group][unit][J] ----
-        for (int e = tid; e < gcnt * upw * J; e += nthr) {
-            const int gl = e % gcnt;
-            const int r = e / gcnt;
-            const int j = r % J;
-            const int ulc = r / J;
-            const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
-            ssb[(gl * upw + ulc) * J + j] = S[(size_t)n * a.G + g0c + gl];
-        }
-        __syncthreads();
-
-        for (int ib = 0; ib < nI; ib += U) {
-            if (ib > 0) load_batch(ib);
+            // ---- stage table / activations / scales: every global load is issued before the
+            // first LDS write, so the prologue costs one memory latency, not three ----
+            const bool stage_x = (geo.nbuf == 2) || (staged_chunk != c);
+            constexpr int XP = BIG_WG ? 1 : 4;                    // 16-B activation pieces per thread (registers)
+            const int xpieces = stage_x ? MB * (KC / 8) : 0;
+            const int spieces_per_col = (gcnt + 7) >> 3;
+            const int spieces = ncols * spieces_per_col;
+            uint4 xv[XP];
+            uint4 sv = make_uint4(0, 0, 0, 0);
+            if (!lut_ready) lut_issue();
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const int ln = (ib + i) * 8 + oct;
-                if (ln < myL) {
-                    const int kl = (l0 + ln) * 64 + sub * 8;          // k inside chunk
-                    const int gl = ((kc0 + kl) >> lg) - g0c;
-                    // scales of the J columns for this k
-                    uint32_t sw[J / 2];
-                    {
-                        const uint32_t* sp =
-                            reinterpret_cast<const uint32_t*>(ssb + (gl * upw + ul) * J);
-                        if constexpr (J == 4) {
-                            const uint2 t = *reinterpret_cast<const uint2*>(sp);
-                            sw[0] = t.x; sw[1] = t.y;
+            for (int r = 0; r < XP; ++r) {
+                const int p = r * nthr + tid;
+                xv[r] = make_uint4(0, 0, 0, 0);
+                if (p < xpieces) {
+                    const int m = p / (KC / 8);
+                    const int kk = (p - m * (KC / 8)) * 8;
+                    if (kk < kc_len) {
+                        const int row = min(a.m0 + m, a.M - 1);
+                        xv[r] = *reinterpret_cast<const uint4*>(A + (size_t)row * a.K + kc0 + kk);
+                    }
+                }
+            }
+            auto scale_src = [&](int p, int& cidx, int& gp) -> const uint16_t* {
+                cidx = p / spieces_per_col;
+                gp = (p - cidx * spieces_per_col) * 8;
+                const int ulc = cidx / J;
+                const int j = cidx - ulc * J;
+                const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
+                return S + (size_t)n * a.G + g0c + gp;
+            };
+            auto scale_load = [&](const uint16_t* sp, int gp) -> uint4 {
+                if (gp + 8 <= gcnt && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0))
+                    return *reinterpret_cast<const uint4*>(sp);
+                uint16_t h[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) h[r] = (gp + r < gcnt) ? sp[r] : (uint16_t)0;
+                return make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16),
+                                  h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
+            };
+            // scales live in LDS as [column][gstride] 32-bit words (fp32, or raw T for PRE)
+            auto scale_store = [&](uint4 t, int cidx, int gp) {
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+                uint32_t o[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint16_t h = (uint16_t)((r & 1) ? (w[r >> 1] >> 16) : (w[r >> 1] & 0xffff));
+                    o[r] = PRE ? (uint32_t)h : __builtin_bit_cast(uint32_t, NT::to_float(h));
+                }
+                uint4* d = reinterpret_cast<uint4*>(ssb + (size_t)cidx * gstride + gp);
+                d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            };
+            int s_cidx = 0, s_gp = 0;
+            if (tid < spieces) sv = scale_load(scale_src(tid, s_cidx, s_gp), s_gp);
+
+            if (!lut_ready) { lut_commit(); lut_ready = true; }
+#pragma unroll
+            for (int r = 0; r < XP; ++r) {
+                const int p = r * nthr + tid;
+                if (p < xpieces) {
+                    const int m = p / (KC / 8);
+                    const int kk = (p - m * (KC / 8)) * 8;
+                    *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = xv[r];
+                }
+            }
+            if (tid < spieces) scale_store(sv, s_cidx, s_gp);
+            // leftovers (large MB*K or many columns): plain load-then-store passes
+            for (int p = XP * nthr + tid; p < xpieces; p += nthr) {
+                const int m = p / (KC / 8);
+                const int kk = (p - m * (KC / 8)) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kk < kc_len)
+                    v = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + kc0 + kk);
+                *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
+            }
+            for (int p = nthr + tid; p < spieces; p += nthr) {
+                int cidx, gp;
+                const uint16_t* sp = scale_src(p, cidx, gp);
+                scale_store(scale_load(sp, gp), cidx, gp);
+            }
+            staged_chunk = c;
+            __syncthreads();
+
+            // ---- stream the lines: consume slot i, then refill it U line slots ahead ----
+            for (int it = 0; it < nI; it += U) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int ln = (it + i) * 8 + oct;
+                    if (ln < myL) {
+                        const int kl = (l0 + ln) * 64 + sub * 8;           // k inside the chunk
+                        const int gl = ((kc0 + kl) >> lg) - g0c;
+                        uint32_t sw[J];
+                        {
+                            const uint32_t sa = (uint32_t)geo.s_off + (uint32_t)buf * (uint32_t)(ss_buf_words * 4) +
+                                                (uint32_t)(ul * J * gstride + gl) * 4;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) sw[j] = lds_ld32(sa + (uint32_t)(j * gstride) * 4);
+                        }
+                        uint4 x[MB];
+                        {
+                            const uint32_t xa = (uint32_t)geo.x_off + (uint32_t)buf * (uint32_t)(MB * KC * 2) + (uint32_t)kl * 2;
+#pragma unroll
+                            for (int m = 0; m < MB; ++m) x[m] = lds_ld128(xa + (uint32_t)(m * KC * 2));
+                        }
+
+                        uint32_t xw[MB][4];
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            xw[m][0] = x[m].x; xw[m][1] = x[m].y; xw[m][2] = x[m].z; xw[m][3] = x[m].w;
+                        }
+                        // column outer, k-pair inner: the 8-k partial sums of a column live in
+                        // MB temporaries; the group scale is applied once per column and line
+                        if constexpr (BITS == 2) {
+#pragma unroll
+                            for (int jp = 0; jp < 4; ++jp) {
+                                float a0[MB], a1[MB];
+#pragma unroll
+                                for (int m = 0; m < MB; ++m) {
+                                    a0[m] = PRE ? acc[2 * jp][m] : 0.f;
+                                    a1[m] = PRE ? acc[2 * jp + 1][m] : 0.f;
+                                }
+#pragma unroll
+                                for (int ww = 0; ww < 4; ++ww) {
+                                    const uint32_t w0 = reinterpret_cast<const uint32_t*>(&q[i][0])[ww];
+                                    const uint32_t addr = __builtin_amdgcn_perm(w0, lane_off, 0x0c0c0400u | ((4u + jp) << 8));
+                                    const uint2 v2 = lds_ld64(addr);
+                                    uint32_t v0 = v2.x, v1 = v2.y;
+                                    if constexpr (PRE) {
+                                        v0 = NT::mul_scale(v0, sw[2 * jp]);
+                                        v1 = NT::mul_scale(v1, sw[2 * jp + 1]);
+                                    }
+#pragma unroll
+                                    for (int m = 0; m < MB; ++m) {
+                                        a0[m] = NT::dot2(v0, xw[m][ww], a0[m]);
+                                        a1[m] = NT::dot2(v1, xw[m][ww], a1[m]);
+                                    }
+                                }
+#pragma unroll
+                                for (int m = 0; m < MB; ++m) {
+                                    acc[2 * jp][m] = PRE ? a0[m] : __builtin_fmaf(a0[m], __builtin_bit_cast(float, sw[2 * jp]), acc[2 * jp][m]);
+                                    acc[2 * jp + 1][m] = PRE ? a1[m] : __builtin_fmaf(a1[m], __builtin_bit_cast(float, sw[2 * jp + 1]), acc[2 * jp + 1][m]);
+                                }
+                            }
                         } else {
 #pragma unroll
-                            for (int h = 0; h < J / 8; ++h) {
-                                const uint4 t = reinterpret_cast<const uint4*>(sp)[h];
-                                sw[4 * h + 0] = t.x; sw[4 * h + 1] = t.y;
-                                sw[4 * h + 2] = t.z; sw[4 * h + 3] = t.w;
+                            for (int j = 0; j < J; ++j) {
+                                float al[MB];
+#pragma unroll
+                                for (int m = 0; m < MB; ++m) al[m] = PRE ? acc[j][m] : 0.f;
+#pragma unroll
+                                for (int ww = 0; ww < 4; ++ww) {
+                                    uint32_t w[NP];
+#pragma unroll
+                                    for (int pl = 0; pl < NP; ++pl)
+                                        w[pl] = reinterpret_cast<const uint32_t*>(&q[i][pl])[ww];
+                                    uint32_t addr;
+                                    if constexpr (BITS == 4)
+                                        addr = __builtin_amdgcn_perm(w[0], lane_off, 0x0c0c0400u | ((4u + j) << 8));
+                                    else
+                                        addr = (field<BITS>(w, j) << 7) | lane_off;
+                                    uint32_t v = lds_ld32(addr);
+                                    if constexpr (PRE) v = NT::mul_scale(v, sw[j]);
+#pragma unroll
+                                    for (int m = 0; m < MB; ++m) al[m] = NT::dot2(v, xw[m][ww], al[m]);
+                                }
+#pragma unroll
+                                for (int m = 0; m < MB; ++m)
+                                    acc[j][m] = PRE ? al[m] : __builtin_fmaf(al[m], __builtin_bit_cast(float, sw[j]), acc[j][m]);
                             }
                         }
-                    }
-                    uint4 x[MB];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-                        x[m] = *reinterpret_cast<const uint4*>(xsb + (size_t)m * KC + kl);
 
+                        // refill this slot U line slots ahead
+                        const int ln2 = ln + U * 8;
+                        if (ln2 < myL) {
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        uint32_t w[NP];
-#pragma unroll
-                        for (int pl = 0; pl < NP; ++pl)
-                            w[pl] = reinterpret_cast<const uint32_t*>(&q[i][pl])[ww];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            const uint32_t idx = field<BITS>(w, j);
-                            const uint32_t v = lut_lane[idx << lsh];
-                            const uint32_t s = (j & 1) ? (sw[j >> 1] >> 16) : sw[j >> 1];
-                            const uint32_t ws = NT::mul_scale(v, s);
-#pragma unroll
-                            for (int m = 0; m < MB; ++m)
-                                acc[j][m] = NT::dot2(
-                                    ws, reinterpret_cast<const uint32_t*>(&x[m])[ww], acc[j][m]);
+                            for (int pl = 0; pl < NP; ++pl)
+                                q[i][pl] = *reinterpret_cast<const uint4*>(qrow[pl] + ((kbase + ln2 * 64) >> 1));
                         }
                     }
                 }
             }
         }
-    }
 
-    // ---- reduce: lanes -> wave -> (kw waves) -> output ----
+        // ---- lanes -> wave (DPP) -> kw waves (LDS) -> output ----
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float v = wave_sum(acc[j][m]);
-            if (lane == 0) red[wave * (J * MB) + j * MB + m] = v;
-        }
-    __syncthreads();
-    for (int t = tid; t < upw * J * MB; t += nthr) {
-        const int ulc = t / (J * MB);
-        const int r = t - ulc * (J * MB);
-        const int j = r / MB;
-        const int m = r - j * MB;
-        float sum = 0.f;
-        for (int kp = 0; kp < kw; ++kp) sum += red[(ulc * kw + kp) * (J * MB) + r];
-        const int row = a.m0 + m;
-        if (row < a.M) {
-            const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
-            if (a.splitk == 1)
-                reinterpret_cast<uint16_t*>(a.D)[(size_t)row * a.N + n] = NT::from_float(sum);
-            else
-                a.partial[((size_t)split * a.M + row) * a.N + n] = sum;
+            for (int m = 0; m < MB; ++m) {
+                const float v = wave_sum_dpp(acc[j][m]);
+                if (lane == 0) red[wave * (J * MB) + j * MB + m] = v;
+            }
+        __syncthreads();
+        for (int t = tid; t < upw * J * MB; t += nthr) {
+            const int ulc = t / (J * MB);
+            const int r = t - ulc * (J * MB);
+            const int j = r / MB;
+            const int m = r - j * MB;
+            float sum = 0.f;
+            for (int kp = 0; kp < kw; ++kp) sum += red[(ulc * kw + kp) * (J * MB) + r];
+            const int row = a.m0 + m;
+            if (row < a.M) {
+                const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
+                if (a.splitk == 1)
+                    reinterpret_cast<uint16_t*>(a.D)[(size_t)row * a.N + n] = NT::from_float(sum);
+                else
+                    a.partial[((size_t)split * a.M + row) * a.N + n] = sum;
+            }
         }
     }
 }

@@ -59,8 +59,8 @@ typedef struct flute_template_info {
 
 /* Launch plan chosen for a problem (host logic only, no GPU needed). */
 typedef struct flute_plan {
-    int family;          /* 0 = decode (streaming GEMV, M<=8), 1 = MFMA */
-    int m_block;         /* decode: rows per pass (1/2/4/8); MFMA: 16-row tiles per wave */
+    int family;          /* 0 = decode (streaming GEMV, M<=4), 1 = MFMA */
+    int m_block;         /* decode: rows per pass (1/2/4); MFMA: 16-row tiles per wave */
     int waves;           /* waves per workgroup */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
     int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */
@@ -108,8 +108,16 @@ int flute_num_templates(int num_bits);
 int flute_get_template_info(int num_bits, int template_id, flute_template_info* out);
 
 /* Tuning overrides for the offline tuner / benchmarks; -1 = automatic.
- * family: 0 decode, 1 MFMA.  Process-global, not thread-safe. */
-void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies);
+ * family: 0 decode, 1 MFMA.  prescale: 1 = decode kernel rounds lut*scale per
+ * pair (fp16 only; the reference's exact arithmetic), 0/-1 = scale applied per
+ * 8-k run in fp32.  Process-global, not thread-safe. */
+void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies,
+                         int prescale);
+
+/* Calibration only: stream `bytes` from `src` with the decode kernel's access shape and
+ * no arithmetic (what the HBM path alone costs for a given byte count). */
+int flute_debug_stream_read(const void* src, void* sink, size_t bytes, int bytes_per_wave,
+                            int grid, int block, void* stream);
 
 const char* flute_strerror(int status);
 int flute_abi_version(void);

@@ -165,13 +165,13 @@ def test_forced_splitk_and_kw_variants(env):
             ref = X.float() @ What
             for kw in (1, 2, 4, 8):
                 for splitk in (1, 2, 4):
-                    for copies in (1, 8, 32):
-                        lib.flute_set_overrides(-1, -1, -1, kw, splitk, copies)
+                    for copies, pre in ((1, 0), (8, 1), (32, 0)):
+                        lib.flute_set_overrides(-1, -1, -1, kw, splitk, copies, pre)
                         D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
                         err = rel_err(D, ref)
-                        assert err < FP16_TOL, (M, kw, splitk, copies, err)
+                        assert err < FP16_TOL, (M, kw, splitk, copies, pre, err)
     finally:
-        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
 
 
 def test_mfma_family_for_small_M(env):
@@ -186,11 +186,11 @@ def test_mfma_family_for_small_M(env):
         try:
             for M in (1, 7):
                 X = (torch.randn(M, K) / 100).to(dtype)
-                lib.flute_set_overrides(1, -1, -1, -1, -1, -1)
+                lib.flute_set_overrides(1, -1, -1, -1, -1, -1, -1)
                 D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
                 assert rel_err(D, X.float() @ What) < tol_of(dtype)
         finally:
-            lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+            lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
 
 
 # ---------------------------------------------------------------------------

@@ -54,7 +54,7 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
             except Exception as ex:  # noqa: BLE001
                 fails.append((tag, str(ex)[:200]))
                 print("EXC ", tag, str(ex)[:200], flush=True)
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
     # one-hot exactness through both families
     ks = torch.randint(0, K, (16,), device=dev)
     X = torch.zeros(16, K, device=dev, dtype=dtype)
@@ -73,14 +73,14 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
 
 
 t0 = time.time()
-AUTO = (-1, -1, -1, -1, -1, -1)
+AUTO = (-1, -1, -1, -1, -1, -1, -1)
 for bits, tile_p in [(4, 32), (4, 64), (2, 32), (2, 64), (3, 32)]:
     for dtype in (torch.float16, torch.bfloat16):
         blk = tile_p * (16 if bits == 3 else 16 // bits)
-        case(bits, tile_p, 64, dtype, 1024, 2 * blk, [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 130], [AUTO])
+        case(bits, tile_p, 64, dtype, 1024, 2 * blk, [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 130], [AUTO, (-1, -1, -1, -1, -1, -1, 1)])
     case(bits, tile_p, 128, torch.float16, 4608, blk, [1, 4, 8, 16, 48],
-         [AUTO, (-1, -1, -1, 1, 1, 32), (-1, -1, -1, 2, 2, 8), (-1, -1, -1, 4, 1, 1), (1, -1, -1, -1, 2, 32),
-          (1, 1, 1, -1, 1, 32), (1, 2, 2, -1, 4, 32)])
+         [AUTO, (-1, -1, -1, 1, 1, 32, 0), (-1, -1, -1, 2, 2, 8, 1), (-1, -1, 4, 4, 1, 1, 0), (-1, -1, 16, 8, 1, 1, 1),
+          (1, -1, -1, -1, 2, 32, -1), (1, 1, 1, -1, 1, 32, -1), (1, 2, 2, -1, 4, 32, -1)])
     case(bits, tile_p, 32, torch.float16, 256, blk, [1, 7, 20], [AUTO])
     case(bits, tile_p, 256, torch.bfloat16, 2048, blk, [1, 7, 20], [AUTO])
 case(4, 32, 64, torch.float16, 4096, 4096, [1, 2, 4, 8, 16, 256], [AUTO])

@@ -28,7 +28,7 @@ def run(M, N, K, bits, g, dtype, tid, ovr, steps=300, hot=False):
              "TFLOPs": round(lay.flops() / us / 1e6, 2), "plan": plan}
     except Exception as ex:  # noqa: BLE001
         r = {"M": M, "N": N, "K": K, "bits": bits, "ovr": ovr, "error": str(ex)[:200]}
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1)
+    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
     rows.append(r)
     print(json.dumps(r), flush=True)
     del lay
@@ -36,38 +36,68 @@ def run(M, N, K, bits, g, dtype, tid, ovr, steps=300, hot=False):
 
 
 f16 = torch.float16
-# decode kernel: waves x kw x lut copies x splitk at the headline shape
-for waves in (4, 8):
-    for kw in (1, 2, 4, 8):
-        if kw > waves:
-            continue
-        for copies in (32, 16, 1):
-            run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, copies))
-run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 2, 32))
-run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, 32), hot=True)
-run(1, 4096, 4096, 4, 64, f16, 16, (1, 1, -1, -1, -1, 32))          # MFMA kernel at M=1
-for (n, k) in ((11008, 4096), (4096, 14336), (28672, 8192)):
-    for waves, kw in ((8, 1), (8, 2), (4, 1), (4, 2)):
-        run(1, n, k, 4, 64, f16, 16, (0, -1, waves, kw, 1, 32))
-# M sweep: decode vs MFMA
-for M in (2, 4, 8):
-    run(M, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, 32))
-    run(M, 4096, 4096, 4, 64, f16, 16, (1, 1, -1, -1, -1, 32))
-for M in (16, 32, 64, 256):
-    for mt in (1, 2, 4):
-        if mt * 16 > max(M, 16) * 1:
-            continue
-        for splitk in (1, 2, 4):
-            run(M, 4096, 4096, 4, 64, f16, 16, (1, mt, -1, -1, splitk, 32))
-for M in (16, 256):
-    for mt in (1, 4):
-        run(M, 11008, 4096, 4, 64, f16, 16, (1, mt, -1, -1, -1, 32))
-# other bit widths (bf16 W3 70B shape, W2)
 bf16 = torch.bfloat16
-for waves, kw in ((8, 1), (8, 2), (4, 1)):
-    run(1, 8192, 8192, 3, 64, bf16, 4, (0, -1, waves, kw, 1, 32))
-run(1, 28672, 8192, 3, 64, bf16, 4, (0, -1, 8, 1, 1, 32))
-run(16, 8192, 8192, 3, 64, bf16, 4, (1, 1, -1, -1, -1, 32))
-run(1, 4096, 4096, 2, 64, f16, 4, (0, -1, 8, 2, 1, 32))
+which = sys.argv[1] if len(sys.argv) > 1 else "decode"
+if which == "decode":
+    for waves in (8, 16):
+        for kw in (1, 2, 4, 8):
+            for pre in (0, 1):
+                run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, pre))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 16, 4, 1, -1, 0), hot=True)
+    run(1, 4096, 4096, 4, 64, bf16, 16, (0, -1, 16, 4, 1, -1, 0))
+    for (n, k) in ((11008, 4096), (4096, 14336), (28672, 8192)):
+        for waves, kw in ((16, 1), (16, 2), (8, 1), (8, 2), (16, 4)):
+            run(1, n, k, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 1))
+    for M in (2, 3, 4):
+        run(M, 4096, 4096, 4, 64, f16, 16, (0, -1, -1, -1, -1, -1, 0))
+        run(M, 28672, 8192, 4, 64, f16, 16, (0, -1, -1, -1, -1, -1, 0))
+    for waves, kw in ((8, 1), (8, 2), (8, 4)):
+        run(1, 8192, 8192, 3, 64, bf16, 4, (0, -1, waves, kw, 1, -1, 0))
+    run(1, 28672, 8192, 3, 64, bf16, 4, (0, -1, 8, 1, 1, -1, 0))
+    for waves, kw in ((16, 4), (16, 2), (8, 2)):
+        run(1, 4096, 4096, 2, 64, f16, 4, (0, -1, waves, kw, 1, -1, 0))
+    run(1, 28672, 8192, 2, 64, f16, 4, (0, -1, 16, 1, 1, -1, 0))
+elif which == "calib":
+    import time
+    lib = _lib.get()
+    sink = torch.zeros(16, dtype=torch.int32, device=dev)
+    for total_mb, bpw in ((8, 8192), (8, 16384), (8, 32768), (22, 8192), (117, 16384), (117, 65536), (512, 65536)):
+        nbytes = total_mb * (1 << 20) // bpw * bpw
+        copies = max(1, (300 << 20) // nbytes + 1)
+        bufs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (nbytes // 4,), dtype=torch.int32, device=dev) for _ in range(copies)]
+        for grid, block in ((256, 1024), (512, 512), (1024, 256), (2048, 256), (256, 512)):
+            def step(i):
+                rc = lib.flute_debug_stream_read(bufs[i % copies].data_ptr(), sink.data_ptr(), nbytes, bpw, grid,
+                                                 block, torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, rc
+            for i in range(5):
+                step(i)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            steps = 200
+            with torch.cuda.graph(g):
+                for i in range(steps):
+                    step(i)
+            g.replay(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / steps * 1e3
+            r = {"calib_read_MB": total_mb, "bytes_per_wave": bpw, "grid": grid, "block": block,
+                 "us": round(us, 3), "GBps": round(nbytes / us / 1e3, 1)}
+            rows.append(r); print(json.dumps(r), flush=True)
+        del bufs
+        torch.cuda.empty_cache()
+else:
+    for M in (5, 8, 16, 32, 64, 256):
+        for mt in (1, 2, 4):
+            if mt * 16 > max(M, 16):
+                continue
+            for splitk in (1, 2, 4):
+                run(M, 4096, 4096, 4, 64, f16, 16, (1, mt, -1, -1, splitk, 32, -1))
+    for M in (16, 256):
+        for mt in (1, 4):
+            run(M, 11008, 4096, 4, 64, f16, 16, (1, mt, -1, -1, -1, 32, -1))
+    run(16, 8192, 8192, 3, 64, bf16, 4, (1, 1, -1, -1, -1, 32, -1))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open("gpurun_out/sweep.json", "w"), indent=1)
+json.dump(rows, open(f"gpurun_out/sweep_{which}.json", "w"), indent=1)
