@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "qgemm_decode.h"
 #include "qgemm_mfma.h"
+#include "qgemm_m16.h"
 
 using namespace flute_amd;
 
@@ -83,9 +84,10 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     const int lsh = ilog2(copies);
 
     const int dec_max = (bits == 3) ? 2 : 4;
-    int family = (M <= dec_max) ? 0 : 1;
+    int family = (M <= dec_max) ? 0 : (M <= 16 ? 2 : 1);
     if (g_ovr.family == 0 && M <= dec_max) family = 0;
     if (g_ovr.family == 1) family = 1;
+    if (g_ovr.family == 2 && M <= 16) family = 2;
     p->family = family;
 
     if (family == 0) {
@@ -127,6 +129,40 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->block = (unsigned)(waves * 64);
         p->lds_bytes = geo.total;
         p->lut_copies = (bits == 4) ? 64 : 32;
+    } else if (family == 2) {
+        // M <= 16: column-per-lane MFMA kernel.  R lanes share a unit: pick the smallest R
+        // whose slab count fills the chip; the rest of the parallelism is the in-workgroup
+        // K split (8 waves), a grid-level split only for very narrow layers.
+        const int rmax = (bits == 3) ? 1 : 4;
+        int R = 1;
+        while (R < rmax && (long)units * R / 16 < (long)num_sms * t.sms_multiple) R *= 2;
+        if (g_ovr.m_block > 0 && g_ovr.m_block <= rmax) R = g_ovr.m_block;
+        const int slabs = units * R / 16;
+        int nw = 8;
+        if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = g_ovr.waves;
+        while (nw > 1 && m16_lds_bytes(bits, R, nw) > (size_t)kMaxLds) nw >>= 1;   // b=3: 16 column tiles
+        int kw = nw;
+        while (kw > 1 && K / kw < 256) kw >>= 1;
+        if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = g_ovr.kw;
+        while (nw % kw) kw >>= 1;
+        while (slabs % (nw / kw)) kw <<= 1;
+        const long wgs = slabs / (nw / kw);
+        int splitk = 1;
+        while (wgs * splitk * 2 <= (long)num_sms && K / (splitk * 2 * kw) >= 256) splitk *= 2;
+        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
+        int kps = round_up(ceil_div(K, splitk), 32 * kw);
+        splitk = ceil_div(K, kps);
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+            splitk >>= 1;
+            kps = round_up(ceil_div(K, splitk), 32 * kw);
+            splitk = ceil_div(K, kps);
+        }
+        if (splitk == 1) kps = K;
+        p->m_block = R; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
+        p->grid = (unsigned)(wgs * splitk);
+        p->block = (unsigned)(nw * 64);
+        p->lds_bytes = m16_lds_bytes(bits, R, nw);
+        p->lut_copies = 64;
     } else {
         int mt = t.tile_m / 16;
         if (g_ovr.m_block > 0) mt = g_ovr.m_block;
@@ -167,10 +203,15 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
 
 QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk) {
     if (family == 0) {
-        const int pre = (g_ovr.prescale > 0) ? 1 : 0;
+        const int pre = (g_ovr.prescale > 0) ? g_ovr.prescale : 0;
         if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, pre);
         if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, pre);
         return decode_kernel_b2(dtype, tile_p, mblk, pre);
+    }
+    if (family == 2) {
+        if (bits == 4) return m16_kernel_b4(dtype, tile_p, mblk);
+        if (bits == 3) return m16_kernel_b3(dtype, tile_p, mblk);
+        return m16_kernel_b2(dtype, tile_p, mblk);
     }
     if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
     if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);
@@ -261,7 +302,7 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.lg = ilog2(group_size);
     a.units = N / ((num_bits == 3) ? 16 : 16 / num_bits);
     a.splitk = p.splitk; a.k_per_split = p.k_per_split; a.kw = p.kw; a.m0 = 0;
-    a.lut_shift = (p.family == 0) ? 0 : ilog2(p.lut_copies);
+    a.lut_shift = (p.family == 1) ? ilog2(p.lut_copies) : 0;
     a.lds_budget = kMaxLds;
 
     QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block);

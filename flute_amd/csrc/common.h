@@ -163,6 +163,34 @@ __device__ __forceinline__ uint32_t lds_base_of(char* smem) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 }
 
+// ---- weight ring: loads hipcc must not count --------------------------------------
+// hipcc cannot carry vmcnt counts over a loop back-edge and drains the ring with
+// s_waitcnt vmcnt(0) at every loop header (r01: compute and HBM time ADDED instead of
+// overlapping).  The ring therefore uses inline-asm loads, invisible to the compiler's
+// bookkeeping, and explicit counted waits that name the destination registers
+// (cdna_hip_programming.md 5.7 form ii).  Loads retire in order, so compiler-issued
+// loads in between can only make a counted wait conservative, never unsafe.
+// The ring registers must never be copied between the load and its wait (the data is
+// not there yet), so ring slots are kept in this vector type from load to use.
+typedef uint32_t ring16_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ ring16_t ring_load16(const void* p) {
+    ring16_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// wait until at most N vector-memory ops are outstanding; the listed registers become
+// valid here (the "+v" ties every later use of them behind the wait)
+template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a, ring16_t& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a, ring16_t& b, ring16_t& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

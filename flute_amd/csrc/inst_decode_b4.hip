@@ -5,6 +5,11 @@
 #include "qgemm_decode.h"
 namespace flute_amd {
 QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre) {
+    // ablation builds (tools/sweep.py ablate): pre = 100 + DBG
+    if (pre == 101) return (QGemmKernel)qgemv_kernel<F16, 4, 32, 1, false, 1>;
+    if (pre == 102) return (QGemmKernel)qgemv_kernel<F16, 4, 32, 1, false, 2>;
+    if (pre == 103) return (QGemmKernel)qgemv_kernel<F16, 4, 32, 1, false, 3>;
+    pre = pre > 0;
     if (tile_p == 32 && mb == 1) {
         if (dtype == 0) return pre ? (QGemmKernel)qgemv_kernel<F16, 4, 32, 1, true> : (QGemmKernel)qgemv_kernel<F16, 4, 32, 1, false>;
         return (QGemmKernel)qgemv_kernel<BF16, 4, 32, 1, false>;

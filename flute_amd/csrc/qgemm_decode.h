@@ -32,7 +32,11 @@
 namespace flute_amd {
 
 template <int BITS> struct DecCfg {
-    static constexpr int U = (BITS == 3) ? 4 : 8;               // lines in flight per lane
+#ifndef FLUTE_DEC_CK
+#define FLUTE_DEC_CK 2
+#endif
+    static constexpr int CK = (BITS == 3) ? 1 : FLUTE_DEC_CK;   // adjacent 16-B pieces per lane and slot
+    static constexpr int U = 4;                                 // slots in flight per lane (U*CK loads)
     static constexpr int LUT_BYTES = (BITS == 3) ? 64 * 128 : 65536;
 };
 
@@ -63,7 +67,7 @@ __host__ __device__ inline DecodeGeom decode_geom(int bits, int mb, int lg, int 
     int kc = (krange + 511) & ~511;
     g.nbuf = 1;
     auto need = [&](int kcc, int nb) {
-        const long gc = (((kcc >> lg) + 1) + 7) & ~7L;       // group stride, multiple of 8 words
+        const long gc = (((kcc >> lg) + 1) + 7) & ~7L;       // staged groups, multiple of 8
         return (long)lut + (long)nb * ((long)mb * kcc * 2 + gc * ncols * 4) + red + 64;
     };
     if (need(kc, 1) > lds_budget) {
@@ -94,21 +98,25 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return (v + r1) + (r2 + r3);
 }
 
-template <typename T, int BITS, int TILEP, int MB, bool PRE>
+// DBG (ablation builds only): bit 0 = skip the LDS table lookups, bit 1 = skip the weight loads
+template <typename T, int BITS, int TILEP, int MB, bool PRE, int DBG = 0>
 __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const QGemmArgs a) {
     using L = Layout<BITS>;
     using NT = Num<T>;
     constexpr int J = L::J;
     constexpr int NP = L::NPLANES;
-    constexpr int U = DecCfg<BITS>::U;
+    constexpr int U = (dec_max_threads(BITS, MB) == 1024) ? 3 : DecCfg<BITS>::U;   // 128-VGPR variants
+    constexpr int CK = DecCfg<BITS>::CK;
+    constexpr int LPS = 8 * CK;            // 64-k lines covered by one wave-wide slot
+    constexpr int LSH = (CK == 2) ? 2 : 3; // lanes per line = 8 / CK
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int lane = tid & 63;
-    const int sub = lane & 7;            // 16-B piece inside the 128-B line
-    const int oct = lane >> 3;           // which of the 8 lines of one wave-wide load
+    const int sub = lane & ((8 / CK) - 1);   // (16*CK)-byte piece inside the 128-B line
+    const int oct = lane >> LSH;             // which of the LPS lines of one wave-wide slot
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = nthr >> 6;
     const int kw = a.kw;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
         const uint32_t* qrow[NP];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u, pl, a.N) * row_words + sub * 4;
+            qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u, pl, a.N) * row_words + sub * (4 * CK);
 
         float acc[J][MB];
 #pragma unroll
@@ -204,10 +212,10 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             const int buf = (geo.nbuf == 2) ? (c & 1) : 0;
             const int kc_len = min(KC, kend - kc0);
             const int Lc = kc_len >> 6;                              // 64-k lines in this chunk
-            const int Lw = (((Lc + kw - 1) / kw) + 7) & ~7;          // lines per wave, multiple of 8
+            const int Lw = (((Lc + kw - 1) / kw) + LPS - 1) & ~(LPS - 1);   // lines per wave
             const int l0 = kpart * Lw;
             const int myL = max(0, min(Lw, Lc - l0));                // lines of this wave
-            const int nI = (myL + 7) >> 3;                           // line slots per lane
+            const int nI = (myL + LPS - 1) / LPS;                    // slots per lane
             const int g0c = kc0 >> lg;
             const int gcnt = ((kc0 + kc_len - 1) >> lg) - g0c + 1;
             uint16_t* xsb = xs + (size_t)buf * MB * KC;
@@ -215,16 +223,23 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             const int kbase = kc0 + l0 * 64;                         // first k of this wave
 
             // ---- weight loads of the first U line slots go out before anything waits ----
-            uint4 q[U][NP];
+            ring16_t q[U][NP][CK];
+            constexpr int RING_SLOT = NP * CK;               // loads per slot
+            // Ring loads are UNCONDITIONAL (line index clamped into the wave's range): a load
+            // inside a branch makes hipcc lose count of the outstanding loads and drain the
+            // ring with s_waitcnt vmcnt(0) before every slot.
+            const int lnmax = max(myL, 1) - 1;
+            auto ring_load = [&](int i, int ln) {
+                const int lc = min(ln, lnmax);
+                const int kk = (myL > 0) ? kbase + lc * 64 : 0;        // wave without lines: stay inside the row
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const int ln = i * 8 + oct;
-                if (ln < myL) {
+                for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        q[i][pl] = *reinterpret_cast<const uint4*>(qrow[pl] + ((kbase + ln * 64) >> 1));
-                }
-            }
+                    for (int ck = 0; ck < CK; ++ck)
+                        q[i][pl][ck] = ring_load16(qrow[pl] + (kk >> 1) + ck * 4);
+            };
+#pragma unroll
+            for (int i = 0; i < U; ++i) ring_load(i, i * LPS + oct);
 
             // ---- stage table / activations / scales: every global load is issued before the
             // first LDS write, so the prologue costs one memory latency, not three ----
@@ -250,8 +265,10 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                 }
             }
             auto scale_src = [&](int p, int& cidx, int& gp) -> const uint16_t* {
-                cidx = p / spieces_per_col;
-                gp = (p - cidx * spieces_per_col) * 8;
+                // consecutive threads take consecutive columns: conflict-free LDS writes below
+                const int gpi = p / ncols;
+                cidx = p - gpi * ncols;
+                gp = gpi * 8;
                 const int ulc = cidx / J;
                 const int j = cidx - ulc * J;
                 const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
@@ -275,12 +292,15 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                     const uint16_t h = (uint16_t)((r & 1) ? (w[r >> 1] >> 16) : (w[r >> 1] & 0xffff));
                     o[r] = PRE ? (uint32_t)h : __builtin_bit_cast(uint32_t, NT::to_float(h));
                 }
-                uint4* d = reinterpret_cast<uint4*>(ssb + (size_t)cidx * gstride + gp);
-                d[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (gp + r < gstride) ssb[(size_t)(gp + r) * ncols + cidx] = o[r];
             };
             int s_cidx = 0, s_gp = 0;
-            if (tid < spieces) sv = scale_load(scale_src(tid, s_cidx, s_gp), s_gp);
+            if (tid < spieces) {
+                const uint16_t* sp0 = scale_src(tid, s_cidx, s_gp);   // sets s_cidx / s_gp first
+                sv = scale_load(sp0, s_gp);
+            }
 
             if (!lut_ready) { lut_commit(); lut_ready = true; }
 #pragma unroll
@@ -309,33 +329,44 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             }
             staged_chunk = c;
             __syncthreads();
+            // Every load issued so far has landed (in-order retirement: the staging loads above
+            // were consumed).  Tell hipcc so: otherwise it guards registers last written by a
+            // staging load with s_waitcnt vmcnt(0) at the loop header and drains the ring.
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), lgkmcnt/expcnt untouched
 
             // ---- stream the lines: consume slot i, then refill it U line slots ahead ----
             for (int it = 0; it < nI; it += U) {
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
-                    const int ln = (it + i) * 8 + oct;
+                    const int ln = (it + i) * LPS + oct;
+                    // slot i is valid once at most the (U-1) younger slots are outstanding
+                    if constexpr (NP == 1 && CK == 2) ring_wait<(U - 1) * RING_SLOT>(q[i][0][0], q[i][0][1]);
+                    else if constexpr (NP == 3) ring_wait<(U - 1) * RING_SLOT>(q[i][0][0], q[i][1][0], q[i][2][0]);
+                    else ring_wait<(U - 1) * RING_SLOT>(q[i][0][0]);
                     if (ln < myL) {
-                        const int kl = (l0 + ln) * 64 + sub * 8;           // k inside the chunk
+                        const int kl = (l0 + ln) * 64 + sub * (8 * CK);    // k inside the chunk
                         const int gl = ((kc0 + kl) >> lg) - g0c;
                         uint32_t sw[J];
                         {
                             const uint32_t sa = (uint32_t)geo.s_off + (uint32_t)buf * (uint32_t)(ss_buf_words * 4) +
-                                                (uint32_t)(ul * J * gstride + gl) * 4;
+                                                (uint32_t)(gl * ncols + ul * J) * 4;
 #pragma unroll
-                            for (int j = 0; j < J; ++j) sw[j] = lds_ld32(sa + (uint32_t)(j * gstride) * 4);
+                            for (int h = 0; h < J / 4; ++h) {
+                                const uint4 t = lds_ld128(sa + 16 * h);
+                                sw[4 * h] = t.x; sw[4 * h + 1] = t.y; sw[4 * h + 2] = t.z; sw[4 * h + 3] = t.w;
+                            }
                         }
-                        uint4 x[MB];
+                        uint32_t xw[MB][4 * CK];
                         {
                             const uint32_t xa = (uint32_t)geo.x_off + (uint32_t)buf * (uint32_t)(MB * KC * 2) + (uint32_t)kl * 2;
 #pragma unroll
-                            for (int m = 0; m < MB; ++m) x[m] = lds_ld128(xa + (uint32_t)(m * KC * 2));
-                        }
-
-                        uint32_t xw[MB][4];
+                            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int m = 0; m < MB; ++m) {
-                            xw[m][0] = x[m].x; xw[m][1] = x[m].y; xw[m][2] = x[m].z; xw[m][3] = x[m].w;
+                                for (int ck = 0; ck < CK; ++ck) {
+                                    const uint4 t = lds_ld128(xa + (uint32_t)(m * KC * 2) + 16 * ck);
+                                    xw[m][4 * ck] = t.x; xw[m][4 * ck + 1] = t.y;
+                                    xw[m][4 * ck + 2] = t.z; xw[m][4 * ck + 3] = t.w;
+                                }
                         }
                         // column outer, k-pair inner: the 8-k partial sums of a column live in
                         // MB temporaries; the group scale is applied once per column and line
@@ -349,8 +380,8 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                                     a1[m] = PRE ? acc[2 * jp + 1][m] : 0.f;
                                 }
 #pragma unroll
-                                for (int ww = 0; ww < 4; ++ww) {
-                                    const uint32_t w0 = reinterpret_cast<const uint32_t*>(&q[i][0])[ww];
+                                for (int ww = 0; ww < 4 * CK; ++ww) {
+                                    const uint32_t w0 = q[i][0][ww >> 2][ww & 3];
                                     const uint32_t addr = __builtin_amdgcn_perm(w0, lane_off, 0x0c0c0400u | ((4u + jp) << 8));
                                     const uint2 v2 = lds_ld64(addr);
                                     uint32_t v0 = v2.x, v1 = v2.y;
@@ -377,17 +408,17 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
 #pragma unroll
                                 for (int m = 0; m < MB; ++m) al[m] = PRE ? acc[j][m] : 0.f;
 #pragma unroll
-                                for (int ww = 0; ww < 4; ++ww) {
+                                for (int ww = 0; ww < 4 * CK; ++ww) {
                                     uint32_t w[NP];
 #pragma unroll
                                     for (int pl = 0; pl < NP; ++pl)
-                                        w[pl] = reinterpret_cast<const uint32_t*>(&q[i][pl])[ww];
+                                        w[pl] = q[i][pl][ww >> 2][ww & 3];
                                     uint32_t addr;
                                     if constexpr (BITS == 4)
                                         addr = __builtin_amdgcn_perm(w[0], lane_off, 0x0c0c0400u | ((4u + j) << 8));
                                     else
                                         addr = (field<BITS>(w, j) << 7) | lane_off;
-                                    uint32_t v = lds_ld32(addr);
+                                    uint32_t v = (DBG & 1) ? addr : lds_ld32(addr);
                                     if constexpr (PRE) v = NT::mul_scale(v, sw[j]);
 #pragma unroll
                                     for (int m = 0; m < MB; ++m) al[m] = NT::dot2(v, xw[m][ww], al[m]);
@@ -398,15 +429,17 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                             }
                         }
 
-                        // refill this slot U line slots ahead
-                        const int ln2 = ln + U * 8;
-                        if (ln2 < myL) {
-#pragma unroll
-                            for (int pl = 0; pl < NP; ++pl)
-                                q[i][pl] = *reinterpret_cast<const uint4*>(qrow[pl] + ((kbase + ln2 * 64) >> 1));
-                        }
                     }
+                    // refill this slot U slots ahead (unconditional, clamped - see ring_load)
+                    ring_load(i, ln + U * LPS);
                 }
+            }
+            // the tail refills are still landing in q[]: drain them before the registers are reused
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                if constexpr (NP == 1 && CK == 2) ring_wait<0>(q[i][0][0], q[i][0][1]);
+                else if constexpr (NP == 3) ring_wait<0>(q[i][0][0], q[i][1][0], q[i][2][0]);
+                else ring_wait<0>(q[i][0][0]);
             }
         }
 

@@ -59,8 +59,9 @@ typedef struct flute_template_info {
 
 /* Launch plan chosen for a problem (host logic only, no GPU needed). */
 typedef struct flute_plan {
-    int family;          /* 0 = decode (streaming GEMV, M<=4), 1 = MFMA */
-    int m_block;         /* decode: rows per pass (1/2/4); MFMA: 16-row tiles per wave */
+    int family;          /* 0 = decode (streaming GEMV, M<=4), 2 = MFMA M<=16, 1 = MFMA M>16 */
+    int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit);
+                            family 1: 16-row tiles per wave */
     int waves;           /* waves per workgroup */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
     int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */

@@ -88,6 +88,24 @@ elif which == "calib":
             rows.append(r); print(json.dumps(r), flush=True)
         del bufs
         torch.cuda.empty_cache()
+elif which == "ablate":
+    for pre in (0, 101, 102, 103):
+        run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, pre), steps=100)
+        run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, pre))
+        run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, pre), hot=True)
+elif which == "m16":
+    for M in (1, 4, 8, 16):
+        for R in (1, 2, 4):
+            for nw, kw in ((8, 8), (8, 4), (4, 4)):
+                run(M, 4096, 4096, 4, 64, f16, 16, (2, R, nw, kw, 1, -1, -1))
+    run(16, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 4, -1, -1))
+    run(16, 4096, 4096, 4, 64, bf16, 16, (2, 4, 8, 8, 1, -1, -1))
+    for (n, k) in ((11008, 4096), (28672, 8192)):
+        for R in (1, 2, 4):
+            run(16, n, k, 4, 64, f16, 16, (2, R, 8, 8, 1, -1, -1))
+        run(16, n, k, 4, 64, f16, 16, (2, 1, 8, 4, 1, -1, -1))
+    run(16, 8192, 8192, 3, 64, bf16, 4, (2, 1, -1, -1, -1, -1, -1))
+    run(16, 4096, 4096, 2, 64, f16, 4, (2, 4, -1, -1, -1, -1, -1))
 else:
     for M in (5, 8, 16, 32, 64, 256):
         for mt in (1, 2, 4):
