@@ -36,7 +36,14 @@ template <int BITS> struct DecCfg {
 #define FLUTE_DEC_CK 2
 #endif
     static constexpr int CK = (BITS == 3) ? 1 : FLUTE_DEC_CK;   // adjacent 16-B pieces per lane and slot
-    static constexpr int U = 4;                                 // slots in flight per lane (U*CK loads)
+#ifndef FLUTE_DEC_U
+#define FLUTE_DEC_U 2
+#endif
+    // slots in flight per lane.  Measured on MI355X (profiles/r01_ring_depth.txt): 2 slots x 2
+    // pieces (4 KiB per wave) is the optimum for b=4/2 - deeper rings get SLOWER (a wave blocks
+    // at its refill load when the memory queues are full and cannot run the compute it
+    // already has data for); the 3-plane b=3 slots are 1 piece per plane and want 4.
+    static constexpr int U = (BITS == 3) ? 4 : FLUTE_DEC_U;
     static constexpr int LUT_BYTES = (BITS == 3) ? 64 * 128 : 65536;
 };
 
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     using NT = Num<T>;
     constexpr int J = L::J;
     constexpr int NP = L::NPLANES;
-    constexpr int U = (dec_max_threads(BITS, MB) == 1024) ? 3 : DecCfg<BITS>::U;   // 128-VGPR variants
+    constexpr int U = DecCfg<BITS>::U;   // 128-VGPR variants
     constexpr int CK = DecCfg<BITS>::CK;
     constexpr int LPS = 8 * CK;            // 64-k lines covered by one wave-wide slot
     constexpr int LSH = (CK == 2) ? 2 : 3; // lanes per line = 8 / CK
@@ -194,52 +201,96 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     const size_t row_words = (size_t)(a.K >> 1);
     int staged_chunk = -1;               // chunk whose activations sit in LDS (nbuf == 1 case)
 
-    for (int ug = wg; ug < ngroups; ug += nwg) {
-        const int u = ug * upw + ul;
-        const uint32_t* qrow[NP];
+    // ---- the wave's work is a flat list of VISITS (unit group, K chunk); its weights form ONE
+    // continuous stream through a U-slot register ring: a refill that runs past the end of a
+    // visit fetches the head of the next one, so the ring only drains when the kernel ends ----
+    const int nchunks = (kend - kbeg + KC - 1) / KC;
+    const int nug = (wg < ngroups) ? (ngroups - wg + nwg - 1) / nwg : 0;
+    const int nvisits = nug * nchunks;
+    struct Visit { int ug, c, kc0, kc_len, l0, myL, nIp, kbase, lnmax; };
+    auto visit_of = [&](int v) -> Visit {
+        Visit t;
+        t.ug = wg + (v / nchunks) * nwg;
+        t.c = v - (v / nchunks) * nchunks;
+        t.kc0 = kbeg + t.c * KC;
+        t.kc_len = min(KC, kend - t.kc0);
+        const int Lc = t.kc_len >> 6;                                        // 64-k lines in the chunk
+        const int Lw = (((Lc + kw - 1) / kw) + LPS - 1) & ~(LPS - 1);         // lines per wave
+        t.l0 = kpart * Lw;
+        t.myL = max(0, min(Lw, Lc - t.l0));
+        const int nI = (t.myL + LPS - 1) / LPS;
+        t.nIp = max(U, ((nI + U - 1) / U) * U);                              // slots, padded to the ring size
+        t.kbase = t.kc0 + ((t.myL > 0) ? t.l0 : 0) * 64;                      // wave without lines: stay in the row
+        t.lnmax = max(t.myL, 1) - 1;
+        return t;
+    };
+    auto rows_of = [&](int ug_, const uint32_t* (&rows)[NP]) {
+        const int u_ = ug_ * upw + ul;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u, pl, a.N) * row_words + sub * (4 * CK);
+            rows[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(u_, pl, a.N) * row_words + sub * (4 * CK);
+    };
 
-        float acc[J][MB];
+    ring16_t q[U][NP][CK];
+    constexpr int RING_SLOT = NP * CK;               // loads per slot
+    Visit cur, nxt;
+    const uint32_t* crow[NP];
+    const uint32_t* nrow[NP];
+    auto load_next_desc = [&](int v) {               // descriptor of visit v+1 (or a clamp onto cur's last line)
+        if (v + 1 < nvisits) {
+            nxt = visit_of(v + 1);
+            rows_of(nxt.ug, nrow);
+        } else {
+            nxt = cur;
+            nxt.kbase = cur.kbase + cur.lnmax * 64;
+            nxt.lnmax = 0;
 #pragma unroll
-        for (int j = 0; j < J; ++j)
+            for (int pl = 0; pl < NP; ++pl) nrow[pl] = crow[pl];
+        }
+    };
+    // Ring loads are UNCONDITIONAL (clamped, never branched around): a load inside a branch makes
+    // hipcc lose count of the outstanding loads, and the counted waits below rely on exactly one
+    // refill per consumed slot.
+    auto ring_load = [&](int i, int s) {             // s: slot index relative to the current visit
+        const bool in_cur = s < cur.nIp;
+        const int sl = in_cur ? s : s - cur.nIp;
+        const int lc = min(sl * LPS + oct, in_cur ? cur.lnmax : nxt.lnmax);
+        const int kk = (in_cur ? cur.kbase : nxt.kbase) + lc * 64;
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+        for (int pl = 0; pl < NP; ++pl) {
+            const uint32_t* base = in_cur ? crow[pl] : nrow[pl];
+#pragma unroll
+            for (int ck = 0; ck < CK; ++ck) q[i][pl][ck] = ring_load16(base + (kk >> 1) + ck * 4);
+        }
+    };
+    if (nvisits > 0) {
+        cur = visit_of(0);
+        rows_of(cur.ug, crow);
+        load_next_desc(0);
+#pragma unroll
+        for (int i = 0; i < U; ++i) ring_load(i, i);
+    }
 
-        int c = 0;
-        for (int kc0 = kbeg; kc0 < kend; kc0 += KC, ++c) {
+    float acc[J][MB];
+    for (int v = 0; v < nvisits; ++v) {
+        const int ug = cur.ug;
+        const int c = cur.c;
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+        }
+        {
             const int buf = (geo.nbuf == 2) ? (c & 1) : 0;
-            const int kc_len = min(KC, kend - kc0);
-            const int Lc = kc_len >> 6;                              // 64-k lines in this chunk
-            const int Lw = (((Lc + kw - 1) / kw) + LPS - 1) & ~(LPS - 1);   // lines per wave
-            const int l0 = kpart * Lw;
-            const int myL = max(0, min(Lw, Lc - l0));                // lines of this wave
-            const int nI = (myL + LPS - 1) / LPS;                    // slots per lane
+            const int kc0 = cur.kc0;
+            const int kc_len = cur.kc_len;
+            const int l0 = cur.l0;
+            const int myL = cur.myL;
             const int g0c = kc0 >> lg;
             const int gcnt = ((kc0 + kc_len - 1) >> lg) - g0c + 1;
             uint16_t* xsb = xs + (size_t)buf * MB * KC;
             uint32_t* ssb = ss + (size_t)buf * ss_buf_words;
-            const int kbase = kc0 + l0 * 64;                         // first k of this wave
-
-            // ---- weight loads of the first U line slots go out before anything waits ----
-            ring16_t q[U][NP][CK];
-            constexpr int RING_SLOT = NP * CK;               // loads per slot
-            // Ring loads are UNCONDITIONAL (line index clamped into the wave's range): a load
-            // inside a branch makes hipcc lose count of the outstanding loads and drain the
-            // ring with s_waitcnt vmcnt(0) before every slot.
-            const int lnmax = max(myL, 1) - 1;
-            auto ring_load = [&](int i, int ln) {
-                const int lc = min(ln, lnmax);
-                const int kk = (myL > 0) ? kbase + lc * 64 : 0;        // wave without lines: stay inside the row
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                    for (int ck = 0; ck < CK; ++ck)
-                        q[i][pl][ck] = ring_load16(qrow[pl] + (kk >> 1) + ck * 4);
-            };
-#pragma unroll
-            for (int i = 0; i < U; ++i) ring_load(i, i * LPS + oct);
 
             // ---- stage table / activations / scales: every global load is issued before the
             // first LDS write, so the prologue costs one memory latency, not three ----
@@ -334,8 +385,8 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             // staging load with s_waitcnt vmcnt(0) at the loop header and drains the ring.
             __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), lgkmcnt/expcnt untouched
 
-            // ---- stream the lines: consume slot i, then refill it U line slots ahead ----
-            for (int it = 0; it < nI; it += U) {
+            // ---- stream the lines: consume slot i, then refill it U slots ahead ----
+            for (int it = 0; it < cur.nIp; it += U) {
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
                     const int ln = (it + i) * LPS + oct;
@@ -430,18 +481,17 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                         }
 
                     }
-                    // refill this slot U slots ahead (unconditional, clamped - see ring_load)
-                    ring_load(i, ln + U * LPS);
+                    // refill this slot U slots ahead: same visit, or the head of the next one
+                    ring_load(i, it + i + U);
                 }
             }
-            // the tail refills are still landing in q[]: drain them before the registers are reused
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                if constexpr (NP == 1 && CK == 2) ring_wait<0>(q[i][0][0], q[i][0][1]);
-                else if constexpr (NP == 3) ring_wait<0>(q[i][0][0], q[i][1][0], q[i][2][0]);
-                else ring_wait<0>(q[i][0][0]);
-            }
         }
+        // advance the stream descriptors (the ring already holds the next visit's first U slots)
+        cur = nxt;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) crow[pl] = nrow[pl];
+        load_next_desc(v + 1);
+        if (c != nchunks - 1) continue;
 
         // ---- lanes -> wave (DPP) -> kw waves (LDS) -> output ----
 #pragma unroll
@@ -467,6 +517,15 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
                 else
                     a.partial[((size_t)split * a.M + row) * a.N + n] = sum;
             }
+        }
+    }
+    // the last refills are clamped re-reads still landing in q[]: drain before the wave ends
+    if (nvisits > 0) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if constexpr (NP == 1 && CK == 2) ring_wait<0>(q[i][0][0], q[i][0][1]);
+            else if constexpr (NP == 3) ring_wait<0>(q[i][0][0], q[i][1][0], q[i][2][0]);
+            else ring_wait<0>(q[i][0][0]);
         }
     }
 }

@@ -88,6 +88,13 @@ elif which == "calib":
             rows.append(r); print(json.dumps(r), flush=True)
         del bufs
         torch.cuda.empty_cache()
+elif which == "ring":
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0), steps=100)
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 8, 1, 1, -1, 0), steps=100)
+    run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, 0))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 16, 4, 1, -1, 0))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 16, 2, 1, -1, 0))
 elif which == "ablate":
     for pre in (0, 101, 102, 103):
         run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, pre), steps=100)
