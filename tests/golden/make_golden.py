@@ -147,3 +147,15 @@ if __name__ == "__main__":
     higgs_case("higgs_w4_v2_f16", 4, 2, f16, 128, 256, 64, 7)
     higgs_case("higgs_w3_v2_bf16", 3, 2, bf16, 128, 512, 64, 8)
     higgs_case("higgs_w2_v1_f16", 2, 1, f16, 128, 256, 64, 9)
+
+
+def template_map():
+    """Reference template id -> TileP (data/qgemm_kernel_raw_generated_configs.pth):
+    the gfx950 table must keep this map so reference-packed weights keep their id."""
+    import json
+    m = {f"{b}:{t}": v["TileP"] for (b, t), v in sorted(pkg.TEMPLATE_CONFIGS.items())}
+    json.dump(m, open(os.path.join(HERE, "ref_template_tilep.json"), "w"))
+
+
+if __name__ == "__main__":
+    template_map()

@@ -1,0 +1,106 @@
+"""C-ABI library: loads, exports every symbol include/flute_amd.h declares, and its
+host-side logic (template table, launch planning, error codes) behaves.  No GPU."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+
+from flute_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "flute_amd.h")).read()
+    declared = set(re.findall(r"\b(flute_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"flute_status", "flute_dtype"}
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in flute_amd.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def test_template_table_keeps_reference_tilep_map():
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_template_tilep.json")))
+    lib = _lib.get()
+    assert lib.flute_num_templates(4) == 144 and lib.flute_num_templates(3) == 36
+    assert lib.flute_num_templates(2) == 36 and lib.flute_num_templates(5) == 0
+    n = 0
+    for key, tile_p in ref.items():
+        b, t = map(int, key.split(":"))
+        info = _lib.TemplateInfo()
+        assert lib.flute_get_template_info(b, t, info) == 0
+        assert info.tile_p == tile_p, (b, t)
+        assert info.tile_k == 64 and info.sms_multiple in (1, 2, 4)
+        n += 1
+    assert n == 216
+    info = _lib.TemplateInfo()
+    assert lib.flute_get_template_info(4, 144, info) == -3
+    assert lib.flute_get_template_info(7, 0, info) == -1
+
+
+def test_error_messages_match_reference_prefixes():
+    # flute/tune.py:160-167 string-matches these
+    assert _lib.strerror(-3).startswith("Unsupported template_id value")
+    assert _lib.strerror(-1).startswith("Unsupported num_bits value")
+    assert _lib.strerror(-2).startswith("Unsupported group_size value")
+    assert "invalid argument" in _lib.strerror(-6)
+    with pytest.raises(RuntimeError, match="Unsupported template_id value"):
+        _lib.check(-3)
+
+
+def plan(M, N, K, bits=4, g=64, tid=16, sms=256, ws=64 << 20, dtype=0):
+    p = _lib.Plan()
+    rc = _lib.get().flute_qgemm_plan(dtype, bits, g, M, N, K, tid, sms, ws, p)
+    return rc, p
+
+
+def test_plan_families_and_invariants():
+    for bits, tid, dec_max in ((4, 16, 4), (2, 4, 4), (3, 4, 2)):
+        for M in (1, 2, 3, 4, 5, 8, 16, 17, 64, 256, 1000):
+            rc, p = plan(M, 4096, 4096, bits=bits, tid=tid)
+            assert rc == 0
+            want = 0 if M <= dec_max else (2 if M <= 16 else 1)
+            assert p.family == want, (bits, M, p.family)
+            assert p.grid >= 1 and p.block % 64 == 0 and 64 <= p.block <= 1024
+            assert p.lds_bytes <= 160 * 1024
+            assert p.waves * 64 == p.block and p.waves % p.kw == 0
+            if p.splitk > 1:
+                assert p.workspace_needed == p.splitk * M * 4096 * 4 <= 64 << 20
+                assert p.k_per_split * p.splitk >= 4096 and p.k_per_split % 64 == 0
+            else:
+                assert p.workspace_needed == 0 and p.k_per_split == 4096
+    # no workspace -> never a grid-level K split
+    for M in (1, 16, 64):
+        rc, p = plan(M, 512, 16384, ws=0)
+        assert rc == 0 and p.splitk == 1
+    # decode kernel: persistent grid never exceeds the unit groups
+    rc, p = plan(1, 28672, 8192)
+    assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4
+
+
+def test_plan_rejects_bad_arguments():
+    assert plan(1, 4096, 4096, bits=5)[0] == -1
+    assert plan(1, 4096, 4096, g=48)[0] == -2
+    assert plan(1, 4096, 4096, tid=999)[0] == -3
+    assert plan(1, 4096, 4096, bits=3, tid=0)[0] == -3      # 3-bit has no TileP=64 layout (utils.py:137-139)
+    assert plan(1, 4096 + 16, 4096)[0] == -4                # N not a multiple of the packing block
+    assert plan(1, 4096, 4096 + 32)[0] == -4                # K % 64
+    assert plan(1, 4096, 4096, g=256, tid=16)[0] == 0
+    assert plan(1, 4096, 4096, dtype=3)[0] == -7
+    assert _lib.get().flute_qgemm_plan(0, 4, 64, 1, 4096, 4096, 16, 256, 0, None) == -9
+
+
+def test_qgemm_null_and_empty_calls_return_before_launch():
+    lib = _lib.get()
+    args = [0, 4, 64, 0, 4096, 4096, 1024] + [None] * 7 + [0, 16, 256, None]
+    assert lib.flute_qgemm(*args) == 0                      # M == 0: nothing to do
+    args[3] = 1
+    assert lib.flute_qgemm(*args) == -9                     # null pointers are refused, no launch
+    args[6] = 7
+    assert lib.flute_qgemm(*args) == -4                     # P inconsistent with N
+    assert lib.flute_hadamard(0, None, None, 0, 64, None) == 0
+    assert lib.flute_hadamard(0, None, None, 64, 64, None) == -9

@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference interface (flute_amd.utils / tune / ops /
+integrations) on CPU: packers against the reference-generated fixtures, fake
+(meta) operator implementations, metadata round trips.  No GPU."""
+import numpy as np
+import pytest
+import torch
+
+import flute_amd
+from flute_amd import tune, utils
+from flute_amd.integrations import higgs
+from flute_amd.integrations.base import FluteLinear
+
+
+def tid_for(bits, tile_p):
+    return [t for (b, t), c in sorted(flute_amd.TEMPLATE_CONFIGS.items())
+            if b == bits and c["TileP"] == tile_p][0]
+
+
+def test_pack_matches_reference_fixture(golden):
+    if golden.kind != "kernel":
+        pytest.skip("HIGGS fixture")
+    Q = utils.pack(torch.from_numpy(golden.W), golden.num_bits, [tid_for(golden.num_bits, golden.tile_p)], 256)
+    assert Q.dtype == torch.int16 and np.array_equal(Q.numpy(), golden.Q)
+
+
+def test_qmap2_matches_reference_fixture(golden):
+    if golden.kind == "higgs" and golden.vector_size == 2:
+        pytest.skip("codebook")
+    t2 = utils.make_qmap2_from_qmap(golden.table)
+    assert torch.equal(t2.view(torch.int32), golden.table2.view(torch.int32))
+
+
+def test_pack_errors_and_template_helpers():
+    with pytest.raises(NotImplementedError):
+        utils._pack_3bit(torch.zeros((64, 1024), dtype=torch.uint8), 64)
+    with pytest.raises(ValueError):
+        utils.pack(torch.zeros((64, 128), dtype=torch.uint8), 4, [0, 16], 256)    # mixed TileP
+    with pytest.raises(OverflowError):
+        utils._pack_4bit(torch.full((64, 128), 16, dtype=torch.uint8), 32)
+    with pytest.raises(ValueError):
+        utils.safe_cast(torch.tensor([1.5]), torch.int64)
+    cfg = utils.get_template_config(4, 132, 256)
+    assert cfg == {"tileM": 16, "tileK": 64, "tileP": 32, "blocks": 4 * 256}
+    assert len(utils.get_template_ids(4)) == 144 and len(utils.get_template_ids(3)) == 36
+    assert utils.is_template_supported(1, 4096, 4096, 4, 16, 256)
+    assert not utils.is_template_supported(1, 4096, 4096, 3, 0, 256)
+    assert len(flute_amd.TEMPLATE_CONFIGS) == 216
+    assert set(flute_amd.TEMPLATE_CONFIGS[(4, 0)]) >= {"SMs_Multiple", "Threads", "TileM", "TileK", "TileP", "Stages"}
+
+
+def _meta_args(M=3, N=256, K=128, bits=4, g=64, dtype=torch.float16, lead=()):
+    mk = lambda *s, dt=dtype: torch.empty(*s, dtype=dt, device="meta")
+    return [mk(*lead, M, K), mk(bits * N // 16, K, dt=torch.int16), mk(N, K // g), mk(2 ** bits),
+            mk(2 ** bits, 2 ** bits, 1, dt=torch.float32), mk(64, dt=torch.uint8), bits, g, 16, 256]
+
+
+def test_fake_impl_shapes_and_validation():
+    # flute/ops.py:4-83
+    out = flute_amd.qgemm(*_meta_args())
+    assert out.shape == (3, 256) and out.dtype == torch.float16 and out.device.type == "meta"
+    out = flute_amd.qgemm(*_meta_args(lead=(2, 5)))
+    assert out.shape == (2, 5, 3, 256)
+    a = _meta_args(dtype=torch.bfloat16)
+    out = flute_amd.qgemm_hadamard(*a[:8], 64, *a[8:])
+    assert out.shape == (3, 256) and out.dtype == torch.bfloat16
+    bad = _meta_args()
+    bad[1] = torch.empty(7, 128, dtype=torch.int16, device="meta")
+    with pytest.raises(ValueError):
+        flute_amd.qgemm(*bad)
+    bad = _meta_args()
+    bad[2] = torch.empty(256, 2, dtype=torch.float32, device="meta")
+    with pytest.raises(TypeError):
+        flute_amd.qgemm(*bad)
+    with pytest.raises(TypeError):
+        flute_amd.qgemm(*_meta_args(dtype=torch.float32))
+
+
+def test_no_cpu_kernel_is_registered():
+    a = _meta_args()
+    cpu = [t.to("cpu") if False else (torch.zeros(t.shape, dtype=t.dtype) if isinstance(t, torch.Tensor) else t) for t in a]
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        flute_amd.qgemm(*cpu)
+
+
+def test_tune_metadata_roundtrip_and_key():
+    m = tune.TuneMetaData(M=1, N=4096, K=4096, num_bits=4, group_size=64, num_sms=256,
+                          dtype=torch.bfloat16, device=torch.device("cuda:0"), template_id=16)
+    assert tune.TuneMetaData.from_dict(m.to_dict()) == m
+    with pytest.raises(ValueError):
+        tune.TuneMetaData.from_dict({**m.to_dict(), "dtype": "torch.int8"})
+    assert tune.get_template_key(1, 8, 16, 4, 64, 256, torch.float16) == \
+        tune.get_template_key(9, 8, 16, 4, 64, 256, torch.float16)       # M < 16 shares a template
+    cands = tune.candidate_templates(1, 4096, 4096, 4, 64, 256, torch.float16)
+    assert 1 <= len(cands) < 144
+    assert {flute_amd.TEMPLATE_CONFIGS[(4, t)]["TileP"] for t in cands} == {32, 64}
+
+
+def test_flute_linear_module_surface():
+    lin = FluteLinear(128, 256, 4, 64, template_id=16, workspace_lazy_init=True, bias=True,
+                      device=torch.device("cpu"), dtype=torch.float16)
+    assert lin.weight.shape == (64, 128) and lin.weight.dtype == torch.int16
+    assert lin.scales.shape == (256, 2) and lin.tables.shape == (16,)
+    assert lin.tables2.shape == (16, 16, 1) and lin.tables2.dtype == torch.float32
+    assert lin.get_extra_state() == {"num_bits": 4, "group_size": 64, "template_id": 16}
+    lin.set_extra_state({"num_bits": 4, "group_size": 64, "template_id": 16})
+    with pytest.raises(ValueError):
+        lin.set_extra_state({"num_bits": 3, "group_size": 64, "template_id": 16})
+    sd = lin.state_dict()
+    assert {"weight", "scales", "tables", "tables2", "bias"} <= set(sd)
+    with pytest.raises(NotImplementedError):
+        FluteLinear(128, 256, 4, 64, 16, device=torch.device("cpu"), dtype=torch.float32)
+
+
+def test_higgs_prepare_data_matches_reference_fixture(golden, monkeypatch):
+    """integrations/higgs.py against the fixture produced by the reference's own
+    prepare_data (tune_and_pack redirected to plain packing, as in make_golden.py)."""
+    if golden.kind != "higgs":
+        pytest.skip("kernel fixture")
+
+    def fake_tune_and_pack(inputs, weight, num_bits, group_size, **kw):
+        tid = tid_for(num_bits, 32)
+        return utils.pack(weight, num_bits, [tid], 108), None
+
+    monkeypatch.setattr(tune, "tune_and_pack", fake_tune_and_pack)
+    Q, S, qmap, qmap2, _ = higgs.prepare_data_transposed(
+        golden.weight_higgs, golden.scales_higgs, golden.grid, golden.num_bits, golden.group_size,
+        golden.vector_size, golden.dtype, torch.device("cpu"), example_batch_size=1,
+        check_correctness=False)
+    assert np.array_equal(Q.numpy(), golden.Q)
+    assert torch.equal(S.view(torch.int16), golden.S.view(torch.int16))
+    assert torch.equal(qmap2.view(torch.int32), golden.table2.view(torch.int32))
+
+
+def test_nf_tables():
+    from flute_amd import nf_utils
+    v, p = nf_utils.get_values_pivots(4)
+    assert torch.allclose(v, torch.tensor(nf_utils.NF4_VALUES)) and p.shape == (15,)
+    v3, _ = nf_utils.get_values_pivots(3)
+    assert v3.shape == (8,) and v3.abs().max() == 1
+    W = torch.randn(64, 128)
+    dq, idx, absmax, vals = nf_utils.nf_quantize(W, 4, 64)
+    assert idx.max() <= 15 and dq.shape == W.shape and absmax.shape == (128,)
+    assert nf_utils.nf_quantize_2(W, 4, 64, torch.float16).dtype == torch.float16
+
+
+def test_install_as_flute_alias():
+    flute_amd.install_as_flute()
+    import flute
+    import flute.tune
+    import flute.utils
+    assert flute.qgemm is flute_amd.qgemm and flute.tune.TuneMetaData is tune.TuneMetaData
