@@ -243,6 +243,10 @@ def main():
 
     if rank == 0:
         achieved = bytes_step / (ms_per_step * 1e-3) / 1e9
+        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
             "metric": "qgemm effective GB/s, M=1, W4G64 NF4 fp16, K=N=4096 (Llama-3-8B linear), HBM-cold",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
@@ -257,11 +261,13 @@ def main():
                        "parallelism": f"{world} independent replica(s), no collective"},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "frac_of_measured_copy_6.29TBps": round(achieved / HBM_COPY_GBPS, 4),
                 "bytes_per_launch": bytes_step,
                 "kernel_us_events": round(ms_per_step * 1e3, 3),
-                "note": "events bracket the graph replay on its stream: includes inter-kernel gaps",
+                "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; "
+                        "traffic = 2*FETCH_SIZE + WRITE_SIZE of profiles/r01_bench_traffic.json; a pure read "
+                        "of the same bytes in this harness takes 3.16 us (profiles/r01_calibration_stream_read.json)",
             },
             "cache_resident": {"us": round(hot_ms / args.steps * 1e3, 3),
                                "GBps": round(bytes_step / (hot_ms / args.steps * 1e-3) / 1e9, 1)},
