@@ -20,7 +20,7 @@ class TemplateInfo(ctypes.Structure):
 
 class Plan(ctypes.Structure):
     _fields_ = [
-        ("family", c_int), ("m_block", c_int), ("waves", c_int), ("kw", c_int),
+        ("family", c_int), ("m_block", c_int), ("m_tiles", c_int), ("waves", c_int), ("kw", c_int),
         ("splitk", c_int), ("k_per_split", c_int), ("lut_copies", c_int),
         ("grid", ctypes.c_uint), ("block", ctypes.c_uint),
         ("lds_bytes", c_size_t), ("workspace_needed", c_size_t)]

@@ -84,10 +84,10 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     const int lsh = ilog2(copies);
 
     const int dec_max = (bits == 3) ? 2 : 4;
-    int family = (M <= dec_max) ? 0 : (M <= 16 ? 2 : 1);
+    int family = (M <= dec_max) ? 0 : 2;
     if (g_ovr.family == 0 && M <= dec_max) family = 0;
     if (g_ovr.family == 1) family = 1;
-    if (g_ovr.family == 2 && M <= 16) family = 2;
+    if (g_ovr.family == 2) family = 2;
     p->family = family;
 
     if (family == 0) {
@@ -130,23 +130,39 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->lds_bytes = geo.total;
         p->lut_copies = (bits == 4) ? 64 : 32;
     } else if (family == 2) {
-        // M <= 16: column-per-lane MFMA kernel.  R lanes share a unit: pick the smallest R
-        // whose slab count fills the chip; the rest of the parallelism is the in-workgroup
-        // K split (8 waves), a grid-level split only for very narrow layers.
-        const int rmax = (bits == 3) ? 1 : 4;
+        // M > decode range: column-per-lane MFMA kernel.  MT 16-row tiles per wave (1 for M <= 16),
+        // R lanes share a unit: pick the smallest R whose slab x row-tile count fills the chip; the
+        // rest of the parallelism is the in-workgroup K split, a grid-level split only for very
+        // narrow layers.
+        int mt = (M <= 16) ? 1 : (M <= 32 ? 2 : 4);
+        const int mt_cap = (bits == 3) ? 2 : 4;
+        if (mt > mt_cap) mt = mt_cap;
+        if (t.tile_m / 16 < mt && M > 16) mt = t.tile_m / 16 >= 2 ? t.tile_m / 16 : mt;
+        if (g_ovr.lut_copies == 1 || g_ovr.lut_copies == 2 || g_ovr.lut_copies == 4) mt = g_ovr.lut_copies;
+        if (mt > mt_cap) mt = mt_cap;
+        // instantiated (R, MT): (J/R)*MT <= 16 accumulator tiles, R in {1,2,4}, MT > 1 needs R <= 2
+        auto combo_ok = [&](int r, int m) {
+            if (bits == 3) return r == 1 && m == 1;
+            return (J / r) * m <= 16 && r <= 4 && (m == 1 || r <= 2);
+        };
+        while (mt > 1 && !combo_ok(1, mt) && !combo_ok(2, mt)) mt >>= 1;
+        const int mtiles = ceil_div(M, mt * 16);
         int R = 1;
-        while (R < rmax && (long)units * R / 16 < (long)num_sms * t.sms_multiple) R *= 2;
-        if (g_ovr.m_block > 0 && g_ovr.m_block <= rmax) R = g_ovr.m_block;
+        while (!combo_ok(R, mt)) R *= 2;
+        while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
+        if (g_ovr.m_block > 0 && combo_ok(g_ovr.m_block, mt)) R = g_ovr.m_block;
         const int slabs = units * R / 16;
         int nw = 8;
         if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = g_ovr.waves;
         while (nw > 1 && m16_lds_bytes(bits, R, nw) > (size_t)kMaxLds) nw >>= 1;   // b=3: 16 column tiles
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
+        // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
+        while (kw > 1 && (long)slabs * mtiles / (nw / kw) >= 2L * num_sms * t.sms_multiple && K / kw < 1024) kw >>= 1;
         if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = g_ovr.kw;
         while (nw % kw) kw >>= 1;
         while (slabs % (nw / kw)) kw <<= 1;
-        const long wgs = slabs / (nw / kw);
+        const long wgs = (long)slabs / (nw / kw) * mtiles;
         int splitk = 1;
         while (wgs * splitk * 2 <= (long)num_sms && K / (splitk * 2 * kw) >= 256) splitk *= 2;
         if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
@@ -158,7 +174,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
             splitk = ceil_div(K, kps);
         }
         if (splitk == 1) kps = K;
-        p->m_block = R; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
+        p->m_block = R; p->m_tiles = mt; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
         p->grid = (unsigned)(wgs * splitk);
         p->block = (unsigned)(nw * 64);
         p->lds_bytes = m16_lds_bytes(bits, R, nw);
@@ -201,7 +217,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     return FLUTE_OK;
 }
 
-QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk) {
+QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles) {
     if (family == 0) {
         const int pre = (g_ovr.prescale > 0) ? g_ovr.prescale : 0;
         if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, pre);
@@ -209,9 +225,9 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk) {
         return decode_kernel_b2(dtype, tile_p, mblk, pre);
     }
     if (family == 2) {
-        if (bits == 4) return m16_kernel_b4(dtype, tile_p, mblk);
-        if (bits == 3) return m16_kernel_b3(dtype, tile_p, mblk);
-        return m16_kernel_b2(dtype, tile_p, mblk);
+        if (bits == 4) return m16_kernel_b4(dtype, tile_p, mblk, mtiles);
+        if (bits == 3) return m16_kernel_b3(dtype, tile_p, mblk, mtiles);
+        return m16_kernel_b2(dtype, tile_p, mblk, mtiles);
     }
     if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
     if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);
@@ -305,7 +321,7 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.lut_shift = (p.family == 1) ? ilog2(p.lut_copies) : 0;
     a.lds_budget = kMaxLds;
 
-    QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block);
+    QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles);
     if (!fn) return FLUTE_ERR_TEMPLATE_ID;
     if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
 

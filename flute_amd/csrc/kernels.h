@@ -12,9 +12,9 @@ QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
 // r: lanes sharing one unit's words in the M<=16 kernel (1, 2, 4; b=3: 1)
-QGemmKernel m16_kernel_b4(int dtype, int tile_p, int r);
-QGemmKernel m16_kernel_b3(int dtype, int tile_p, int r);
-QGemmKernel m16_kernel_b2(int dtype, int tile_p, int r);
+QGemmKernel m16_kernel_b4(int dtype, int tile_p, int r, int mt);
+QGemmKernel m16_kernel_b3(int dtype, int tile_p, int r, int mt);
+QGemmKernel m16_kernel_b2(int dtype, int tile_p, int r, int mt);
 QGemmKernel mfma_kernel_b4(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b3(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b2(int dtype, int tile_p, int mt);

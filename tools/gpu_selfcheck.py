@@ -78,10 +78,11 @@ for bits, tile_p in [(4, 32), (4, 64), (2, 32), (2, 64), (3, 32)]:
     for dtype in (torch.float16, torch.bfloat16):
         blk = tile_p * (16 if bits == 3 else 16 // bits)
         case(bits, tile_p, 64, dtype, 1024, 2 * blk, [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 130], [AUTO, (-1, -1, -1, -1, -1, -1, 1)])
-    case(bits, tile_p, 128, torch.float16, 4608, blk, [1, 4, 8, 16, 48],
+    case(bits, tile_p, 128, torch.float16, 4608, blk, [1, 4, 8, 16, 48, 70],
          [AUTO, (-1, -1, -1, 1, 1, 32, 0), (-1, -1, -1, 2, 2, 8, 1), (-1, -1, 4, 4, 1, 1, 0), (-1, -1, 16, 8, 1, 1, 1),
           (1, -1, -1, -1, 2, 32, -1), (1, 1, 1, -1, 1, 32, -1), (1, 2, 2, -1, 4, 32, -1),
-          (2, 1, -1, -1, -1, -1, -1), (2, 2, 8, 4, 2, -1, -1), (2, 4, 4, 1, 1, -1, -1), (2, 4, 8, 8, 1, -1, -1)])
+          (2, 1, -1, -1, -1, -1, -1), (2, 2, 8, 4, 2, -1, -1), (2, 4, 4, 1, 1, -1, -1), (2, 4, 8, 8, 1, -1, -1),
+          (2, 1, -1, -1, -1, 4, -1), (2, 2, 8, 2, 1, 2, -1), (2, 1, 4, 4, 2, 2, -1), (2, 2, -1, -1, -1, 4, -1)])
     case(bits, tile_p, 32, torch.float16, 256, blk, [1, 7, 20], [AUTO])
     case(bits, tile_p, 256, torch.bfloat16, 2048, blk, [1, 7, 20], [AUTO])
 case(4, 32, 64, torch.float16, 4096, 4096, [1, 2, 4, 8, 16, 256], [AUTO])

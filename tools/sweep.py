@@ -100,6 +100,21 @@ elif which == "ablate":
         run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, pre), steps=100)
         run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, pre))
         run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, pre), hot=True)
+elif which == "mt":
+    for M in (16, 32, 64, 256):
+        for R, MT in ((1, 1), (2, 1), (4, 1), (1, 2), (2, 2), (1, 4), (2, 4)):
+            if MT * 16 > max(M, 16):
+                continue
+            for kw in (8, 4, 2):
+                run(M, 4096, 4096, 4, 64, f16, 16, (2, R, 8, kw, 1, MT, -1), steps=200)
+    for M in (16, 256):
+        for R, MT, kw in ((1, 1, 8), (1, 4, 8), (1, 4, 4), (2, 4, 4), (1, 4, 2), (1, 2, 4)):
+            if MT * 16 > max(M, 16):
+                continue
+            run(M, 11008, 4096, 4, 64, f16, 16, (2, R, 8, kw, 1, MT, -1), steps=100)
+    run(256, 4096, 4096, 4, 64, bf16, 16, (2, 1, 8, 8, 1, 4, -1), steps=200)
+    run(256, 4096, 4096, 4, 64, f16, 16, (1, 1, -1, -1, 2, 32, -1), steps=200)
+    run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, -1), steps=100)
 elif which == "m16":
     for M in (1, 4, 8, 16):
         for R in (1, 2, 4):
