@@ -179,6 +179,17 @@ __device__ __forceinline__ ring16_t ring_load16(const void* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// streamed-once data (the packed weights): non-temporal, so the stream does not evict the
+// activations / scales that every workgroup re-reads from L2
+__device__ __forceinline__ ring16_t ring_load16_nt(const void* p) {
+    ring16_t v;
+#ifndef FLUTE_NT     // measured on MI355X (r01): nt on the weight stream is neutral to slightly negative
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+#endif
+    return v;
+}
 // wait until at most N vector-memory ops are outstanding; the listed registers become
 // valid here (the "+v" ties every later use of them behind the wait)
 template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a) {

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
         for (int pl = 0; pl < NP; ++pl) {
             const uint32_t* base = in_cur ? crow[pl] : nrow[pl];
 #pragma unroll
-            for (int ck = 0; ck < CK; ++ck) q[i][pl][ck] = ring_load16(base + (kk >> 1) + ck * 4);
+            for (int ck = 0; ck < CK; ++ck) q[i][pl][ck] = ring_load16_nt(base + (kk >> 1) + ck * 4);
         }
     };
     if (nvisits > 0) {

@@ -88,6 +88,17 @@ elif which == "calib":
             rows.append(r); print(json.dumps(r), flush=True)
         del bufs
         torch.cuda.empty_cache()
+elif which == "quick":
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0), steps=100)
+    run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, 0))
+    run(16, 4096, 4096, 4, 64, f16, 16, (2, 4, 8, 8, 1, 1, -1))
+    run(16, 28672, 8192, 4, 64, f16, 16, (2, 1, 8, 4, 1, 1, -1), steps=100)
+    run(64, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 1, -1))
+    run(256, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, -1), steps=200)
+    run(256, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 2, -1), steps=200)
+    run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, -1), steps=100)
+    run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, -1), steps=100)
 elif which == "ring":
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0), steps=100)
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 8, 1, 1, -1, 0), steps=100)
