@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_int, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libflute_amd.so")
+# FLUTE_AMD_LIB: development builds of the same ABI (e.g. the phase-timestamp build)
+LIB_PATH = os.environ.get("FLUTE_AMD_LIB") or os.path.join(_HERE, "csrc", "libflute_amd.so")
 
 
 class TemplateInfo(ctypes.Structure):

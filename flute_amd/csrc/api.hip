@@ -14,6 +14,7 @@
 #include "qgemm_decode.h"
 #include "qgemm_mfma.h"
 #include "qgemm_m16.h"
+#include "qgemm_tile.h"
 
 using namespace flute_amd;
 
@@ -88,6 +89,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     if (g_ovr.family == 0 && M <= dec_max) family = 0;
     if (g_ovr.family == 1) family = 1;
     if (g_ovr.family == 2) family = 2;
+    if (g_ovr.family == 3) family = 3;
     p->family = family;
 
     if (family == 0) {
@@ -129,7 +131,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->block = (unsigned)(waves * 64);
         p->lds_bytes = geo.total;
         p->lut_copies = (bits == 4) ? 64 : 32;
-    } else if (family == 2) {
+    } else if (family == 2 || family == 3) {
         // M > decode range: column-per-lane MFMA kernel.  MT 16-row tiles per wave (1 for M <= 16),
         // R lanes share a unit: pick the smallest R whose slab x row-tile count fills the chip; the
         // rest of the parallelism is the in-workgroup K split, a grid-level split only for very
@@ -154,7 +156,11 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         const int slabs = units * R / 16;
         int nw = 8;
         if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = g_ovr.waves;
-        while (nw > 1 && m16_lds_bytes(bits, R, nw) > (size_t)kMaxLds) nw >>= 1;   // b=3: 16 column tiles
+        if (family == 3) {
+            while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;
+        } else {
+            while (nw > 1 && m16_lds_bytes(bits, R, nw) > (size_t)kMaxLds) nw >>= 1;   // b=3: 16 column tiles
+        }
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
@@ -177,7 +183,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->m_block = R; p->m_tiles = mt; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
         p->grid = (unsigned)(wgs * splitk);
         p->block = (unsigned)(nw * 64);
-        p->lds_bytes = m16_lds_bytes(bits, R, nw);
+        p->lds_bytes = (family == 3) ? (size_t)tile_geom(bits, R, mt, nw, kMaxLds).total : m16_lds_bytes(bits, R, nw);
         p->lut_copies = 64;
     } else {
         int mt = t.tile_m / 16;
@@ -228,6 +234,11 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, i
         if (bits == 4) return m16_kernel_b4(dtype, tile_p, mblk, mtiles);
         if (bits == 3) return m16_kernel_b3(dtype, tile_p, mblk, mtiles);
         return m16_kernel_b2(dtype, tile_p, mblk, mtiles);
+    }
+    if (family == 3) {
+        if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles);
+        if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
+        return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
     }
     if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
     if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);

@@ -15,6 +15,10 @@ QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
 QGemmKernel m16_kernel_b4(int dtype, int tile_p, int r, int mt);
 QGemmKernel m16_kernel_b3(int dtype, int tile_p, int r, int mt);
 QGemmKernel m16_kernel_b2(int dtype, int tile_p, int r, int mt);
+// LDS-DMA staged successor of the m16 kernels (same (r, mt) combinations)
+QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt);
+QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);
+QGemmKernel tile_kernel_b2(int dtype, int tile_p, int r, int mt);
 QGemmKernel mfma_kernel_b4(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b3(int dtype, int tile_p, int mt);
 QGemmKernel mfma_kernel_b2(int dtype, int tile_p, int mt);

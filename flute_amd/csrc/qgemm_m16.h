@@ -73,6 +73,13 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();
+#ifdef FLUTE_STAMPS   // development build: 100 MHz wall-clock stamps per wave into the (unused) workspace
+    uint64_t stamp[8];
+    stamp[0] = wall_clock64();
+#define FLUTE_STAMP(i) stamp[i] = wall_clock64()
+#else
+#define FLUTE_STAMP(i)
+#endif
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -143,6 +150,7 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
     };
 #pragma unroll
     for (int t = 0; t < D; ++t) ring_issue(t, t);
+    FLUTE_STAMP(4);
 
     // ---- pair table (stride 256 B; 64 copies of 4 B) ----
     {
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
         }
     }
 
+    FLUTE_STAMP(5);
     // ---- wave-private scale table: block of GB groups, layout [i][group][column] (halves) ----
     uint16_t* scw = reinterpret_cast<uint16_t*>(smem + sc_base);
     auto stage_scales = [&](int gblk0) {
@@ -179,8 +188,10 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
     };
     int gblk0 = (kb >> lg) & ~7;                 // first staged group (8-aligned for vector loads)
     if (nsteps > 0) stage_scales(gblk0);
+    FLUTE_STAMP(6);
     __syncthreads();                             // table + scales visible (only barrier before the epilogue)
     __builtin_amdgcn_s_waitcnt(0x0F70);          // hipcc: nothing of yours is outstanding (see decode kernel)
+    FLUTE_STAMP(1);
 
     f32x4_t acc[MT][NMF], run[MT][NMF];
     uint32_t sreg[NMF];                          // current group's scale (raw T in the low half)
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
     for (; t0 + D < nround; t0 += D) ring_turn(std::false_type{}, t0);
     ring_turn(std::true_type{}, t0);                     // also the only turn when nsteps <= D
     if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
+    FLUTE_STAMP(2);
 
     // ---- reduce the kw partial tiles through LDS (one 16-row tile at a time), write rows < M ----
     float* red = reinterpret_cast<float*>(smem + red_base);
@@ -312,6 +324,15 @@ __global__ __launch_bounds__(512) void qgemm_m16_kernel(const QGemmArgs a) {
                 }
         }
     }
+#ifdef FLUTE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);               // stores retired
+    FLUTE_STAMP(3);
+    if (lane == 0 && a.splitk == 1 && a.partial != nullptr) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.partial) + ((size_t)blockIdx.x * nw + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef FLUTE_STAMP
 }
 
 }  // namespace flute_amd

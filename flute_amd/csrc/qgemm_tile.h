@@ -1,0 +1,407 @@
+// MFMA kernel for every M above the decode kernel's range, operands staged by LDS-DMA.
+//
+// gfx950 replacement for qgemm_device (flute/csrc/qgemm_kernel.hpp:617-712).  One
+// v_mfma_f32_16x16x32 consumes 16 weight columns x 32 k x 16 activation rows.  Who computes what
+// is unchanged from the first column-per-lane kernel (r01): a wave owns a SLAB of 16/R units
+// (R lanes share one unit's words and each takes J/R of its fields => J/R column tiles per
+// k-step), MT 16-row tiles of activations, and one K range of the workgroup's in-LDS K split.
+//
+// What changed is how the operands reach the registers.  An MFMA operand wants lane (r, q) to hold
+// 16 B of ROW r (r = lane % 16): 64 lanes, 64 different cache lines.  The texture addresser
+// serves such a load at one lane per clock (measured, tools/ubench/ta_patterns.hip: 61.8 cycles
+// per wave-instruction, 16.6 B/clk/CU, against 17.4 cycles when 4..8 neighbouring lanes share a
+// line) and that, not MFMA, LDS or L2 bandwidth, bounded the r01 kernel (10 % of the MFMA peak
+// at M = 256, 6.6 us of load issue at M = 16).  Here every global access is line-coalesced:
+//   * global_load_lds_dwordx4 (LDS-DMA): lane L fetches 16 B of row L / (4R) (weights; a piece is
+//     16/R rows x R k-steps x 64 B) or row L / 4 (activations; 16 rows x 64 B), written to LDS
+//     lane-linearly; no VGPR round trip, no ds_write;
+//   * the MFMA layout is produced by the ds_read_b128 that follows; the 16-B chunk index inside a
+//     row is XOR-swizzled on the SOURCE address (and identically on the read) so that the reads
+//     are bank-conflict free;
+//   * the ring of in-flight pieces lives in wave-private LDS: no barrier in the main loop, the
+//     wave waits for its own DMA with counted s_waitcnt vmcnt(N).
+// The weights are the MFMA's A operand and the activations its B operand, so the accumulator
+// of lane (r, q) holds output row r and FOUR CONSECUTIVE columns 4q..4q+3: the epilogue stores
+// 8 B per lane (16 B for split-K partials) instead of four 2-B scatters, and all waves of the
+// workgroup take part in the cross-wave K reduction.
+//
+// Arithmetic contract as before: fp16 w^ = round_T(lut * s) with v_pk_mul_f16 (the reference's
+// packbits_utils.hpp:139); bf16 applies the group scale to the fp32 MFMA result of each group run.
+#pragma once
+#include "common.h"
+#include "qgemm_mfma.h"
+
+namespace flute_amd {
+
+constexpr int TILE_GB = 16;          // scale groups per staged block (wave-private table)
+
+struct TileGeom {
+    int scale_bytes;   // wave-private scale table [column tile][group][16 columns]
+    int slot_bytes;    // one ring slot = one macro-step (R k-steps): NP weight + MT*R activation pieces of 1 KB
+    int depth;         // ring slots per wave
+    int wave_bytes;
+    int total;         // dynamic LDS of the launch (main loop carve or epilogue partial tiles)
+};
+
+__host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int waves, int budget) {
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int NP = (bits == 3) ? 3 : 1;
+    const int nmf = J / R;
+    const int lut = (1 << (2 * bits)) * 256;
+    const int lps = NP + mt * R;
+    TileGeom g;
+    g.scale_bytes = nmf * TILE_GB * 32;
+    g.slot_bytes = lps * 1024;
+    int d = ((budget - lut) / waves - g.scale_bytes) / g.slot_bytes;
+    if (d > 6) d = 6;
+    while (d > 1 && (d - 1) * lps > 56) --d;          // vmcnt is a 6-bit counter
+    g.depth = d;
+    g.wave_bytes = g.scale_bytes + d * g.slot_bytes;
+    const int main_bytes = lut + waves * g.wave_bytes;
+    const int epi_bytes = waves * mt * nmf * 1024;
+    g.total = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    return g;
+}
+
+// LDS-DMA: 16 B per lane from `g` to LDS byte `lds_addr + 16 * lane` (wave-uniform base in M0).
+// Invisible to hipcc's s_waitcnt bookkeeping: completion is waited for by hand (dma_wait).
+__device__ __forceinline__ void dma16(const void* g, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// wait until at most `steps` macro-steps (LPS loads each) issued later are still in flight
+template <int LPS> __device__ __forceinline__ void dma_wait(int steps) {
+    switch (steps) {
+        case 0: vm_wait<0>(); break;
+        case 1: vm_wait<LPS>(); break;
+        case 2: vm_wait<2 * LPS>(); break;
+        case 3: vm_wait<(3 * LPS > 63 ? 63 : 3 * LPS)>(); break;
+        case 4: vm_wait<(4 * LPS > 63 ? 63 : 4 * LPS)>(); break;
+        default: vm_wait<(5 * LPS > 63 ? 63 : 5 * LPS)>(); break;
+    }
+}
+
+// chunk swizzles (an involution applied to the source address and to the read address): with
+// them the 16 lanes of every ds_read_b128 lane group hit 16 different 16-B bank slots
+__device__ __forceinline__ int swz_a(int row) { return (4 - (row >> 2)) & 3; }       // 16 rows x 4 chunks
+template <int R> __device__ __forceinline__ int swz_q(int row) {                      // 16/R rows x 4R chunks
+    if constexpr (R == 1) return (4 - (row >> 2)) & 3;
+    else if constexpr (R == 2) return (row >> 1) << 1;
+    else return row << 2;
+}
+
+template <typename T, int BITS, int TILEP, int R, int MT>
+__global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
+    using L = Layout<BITS>;
+    using NT = Num<T>;
+    constexpr int J = L::J;
+    constexpr int NP = L::NPLANES;
+    constexpr int NMF = J / R;                 // column tiles per k-step and row tile
+    constexpr int SU = 16 / R;                 // units per slab
+    constexpr int LPS = NP + MT * R;           // DMA pieces per macro-step
+    constexpr int GB = TILE_GB;
+    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 256;
+    constexpr bool PRE = __is_same(T, F16);
+    static_assert(BITS != 3 || R == 1, "3-bit fields are not byte aligned: R = 1 only");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();
+#ifdef FLUTE_STAMPS   // development build: 100 MHz wall-clock stamps per wave into the (unused) workspace
+    uint64_t stamp[8];
+    stamp[0] = wall_clock64();
+#define FLUTE_STAMP(i) stamp[i] = wall_clock64()
+#else
+#define FLUTE_STAMP(i)
+#endif
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int lane = tid & 63;
+    const int r16 = lane & 15;
+    const int q4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = nthr >> 6;
+    const int kw = a.kw;
+    const int ns = nw / kw;
+    const int sl = wave / kw;
+    const int kpart = wave - sl * kw;
+    const int lg = a.lg;
+
+    int bid = blockIdx.x;
+    const int split = bid % a.splitk;  bid /= a.splitk;
+    const int mtiles = (a.M + MT * 16 - 1) / (MT * 16);
+    const int mtile = bid % mtiles;
+    const int sg = bid / mtiles;
+    const int m0 = mtile * (MT * 16);
+    const int slab = sg * ns + sl;
+    // MFMA role of this lane on the weight side: column r16 of every column tile =
+    // unit (r16 % SU) of the slab, field i*R + (r16 / SU) of that unit in tile i
+    const int ul = r16 % SU;
+    const int f = r16 / SU;
+    const int kbeg = split * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int kpw = (((kend - kbeg + kw - 1) / kw) + 32 * R - 1) / (32 * R) * (32 * R);
+    const int kb = min(kend, kbeg + kpart * kpw);
+    const int ke = min(kend, kb + kpw);
+    const int nsteps = (ke - kb) >> 5;
+    const int nmacro = (nsteps + R - 1) / R;
+
+    const TileGeom geo = tile_geom(BITS, R, MT, nw, a.lds_budget);
+    const int D = geo.depth;
+    const uint32_t sc_base = LUT_BYTES + (uint32_t)wave * geo.wave_bytes;
+    const uint32_t ring0 = sc_base + geo.scale_bytes;
+    const uint32_t slot_bytes = geo.slot_bytes;
+
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(a.A);
+    const uint16_t* S = reinterpret_cast<const uint16_t*>(a.S);
+    const size_t row_words = (size_t)(a.K >> 1);
+
+    // ---- DMA roles: which 16 B of which row this lane fetches for a weight / activation piece ----
+    const int lrow = lane / (4 * R);                                  // weight piece row (unit of the slab)
+    const int qchunk = (lane % (4 * R)) ^ swz_q<R>(lrow);             // source chunk (8 k each) inside the macro-step
+    const uint32_t* qrow[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+        qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(slab * SU + lrow, pl, a.N) * row_words;
+    const int arow = lane >> 2;
+    const int achunk = (lane & 3) ^ swz_a(arow);
+    const uint16_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)      // row >= M: clamped; that accumulator column is never stored
+        xrow[mt] = A + (size_t)min(m0 + mt * 16 + arow, a.M - 1) * a.K;
+    const int klim = a.K - 8;            // a lane never reads past its row (ragged last macro-step)
+
+    auto issue = [&](int t, uint32_t slot_addr) {
+        const int k0 = kb + t * (32 * R);
+        const int kq = min(k0 + qchunk * 8, klim);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dma16(qrow[pl] + (kq >> 1), slot_addr + pl * 1024);
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int ka = min(k0 + s * 32 + achunk * 8, klim);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) dma16(xrow[mt] + ka, slot_addr + (NP + s * MT + mt) * 1024);
+        }
+    };
+    if (nmacro > 0) issue(0, ring0);
+    FLUTE_STAMP(4);
+
+    // ---- MFMA-side addresses inside a slot ----
+    const uint32_t qread = (uint32_t)(ul * (4 * R)) * 16;            // + ((s*4 + q4) ^ swz) * 16
+    const int qswz = swz_q<R>(ul);
+    const uint32_t aread = (uint32_t)(r16 * 4 + (q4 ^ swz_a(r16))) * 16;
+    uint32_t selv[NMF];
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) selv[i] = 0x0c0c0400u | ((4u + (uint32_t)(i * R + f)) << 8);   // b=4: byte j of the word
+    const uint32_t lane_off = (uint32_t)lane * 4;
+
+    // ---- pair table (stride 256 B; 64 copies of 4 B) ----
+    {
+        constexpr int ENT = 1 << (2 * BITS);
+        for (int p = tid; p < ENT * 4; p += nthr) {
+            const uint32_t v = a.QM2[p >> 2];
+            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 2) * 256 + (p & 3) * 64);
+            const uint4 vv = make_uint4(v, v, v, v);
+            d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
+        }
+    }
+    FLUTE_STAMP(5);
+
+    // ---- wave-private scale table: block of GB groups, layout [tile][group][column] (halves);
+    // column c of tile i is the weight-side MFMA column c ----
+    int ncolB[NMF];
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) ncolB[i] = unit_col0<BITS, TILEP>(slab * SU + ul) + (i * R + f) * TILEP;
+    uint16_t* scw = reinterpret_cast<uint16_t*>(smem + sc_base);
+    auto stage_scales = [&](int gblk0) {
+        // lane (c = lane&15, o = lane>>4 < GB/8) fetches groups [gblk0 + 8o, +8) of its column
+        if (q4 < GB / 8) {
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int g0 = gblk0 + q4 * 8;
+                const uint16_t* sp = S + (size_t)ncolB[i] * a.G + g0;
+                uint16_t hv[8];
+                if (g0 + 8 <= a.G && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0)) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(sp);
+                    hv[0] = t.x & 0xffff; hv[1] = t.x >> 16; hv[2] = t.y & 0xffff; hv[3] = t.y >> 16;
+                    hv[4] = t.z & 0xffff; hv[5] = t.z >> 16; hv[6] = t.w & 0xffff; hv[7] = t.w >> 16;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) hv[r] = (g0 + r < a.G) ? sp[r] : (uint16_t)0;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) scw[(i * GB + q4 * 8 + r) * 16 + r16] = hv[r];
+            }
+        }
+    };
+    int gblk0 = (kb >> lg) & ~7;                 // first staged group (8-aligned for vector loads)
+    if (nsteps > 0) stage_scales(gblk0);
+    FLUTE_STAMP(6);
+    // the rest of the ring (the table loads above travelled behind slot 0 only)
+    for (int t = 1; t < D && t < nmacro; ++t) issue(t, ring0 + (uint32_t)t * slot_bytes);
+    __syncthreads();                             // table + scales visible (only barrier before the epilogue)
+    FLUTE_STAMP(1);
+
+    f32x4_t acc[MT][NMF], run[MT][NMF];
+    uint32_t sreg[NMF];                          // fp16: current group's scale of weight column r16 (raw T, low half)
+    float sf[NMF][4];                            // bf16: current group's scales of the accumulator's 4 columns
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+        sreg[i] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sf[i][e] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            run[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    int cur_group = -1;
+    auto fold_run = [&]() {
+#pragma unroll
+        for (int i = 0; i < NMF; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][i][e] = __builtin_fmaf(run[mt][i][e], sf[i][e], acc[mt][i][e]);
+                run[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    uint32_t slot = ring0;                       // slot of macro-step t
+    int slot_idx = 0;
+    for (int t = 0; t < nmacro; ++t) {
+        dma_wait<LPS>(min(D - 1, nmacro - 1 - t));
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int ks = t * R + s;
+            if (ks < nsteps) {                                            // wave-uniform
+                const int k0 = kb + ks * 32;
+                const int grp = k0 >> lg;
+                if (grp != cur_group) {
+                    if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
+                    if (grp >= gblk0 + GB) {                              // next block of scales
+                        gblk0 = grp & ~7;
+                        stage_scales(gblk0);
+                    }
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int i = 0; i < NMF; ++i)
+                            sreg[i] = *reinterpret_cast<const uint16_t*>(
+                                smem + sc_base + (uint32_t)((i * GB + (grp - gblk0)) * 16 + r16) * 2);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NMF; ++i) {
+                            const uint2 h = lds_ld64(sc_base + (uint32_t)((i * GB + (grp - gblk0)) * 16 + q4 * 4) * 2);
+                            sf[i][0] = NT::to_float((uint16_t)(h.x & 0xffff)); sf[i][1] = NT::to_float((uint16_t)(h.x >> 16));
+                            sf[i][2] = NT::to_float((uint16_t)(h.y & 0xffff)); sf[i][3] = NT::to_float((uint16_t)(h.y >> 16));
+                        }
+                    }
+                    cur_group = grp;
+                }
+                uint32_t qw[NP][4];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const uint4 v = lds_ld128(slot + pl * 1024 + qread + (uint32_t)(((s * 4 + q4) ^ qswz) * 16));
+                    qw[pl][0] = v.x; qw[pl][1] = v.y; qw[pl][2] = v.z; qw[pl][3] = v.w;
+                }
+                u32x4_t af[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint4 v = lds_ld128(slot + (NP + s * MT + mt) * 1024 + aread);
+                    af[mt] = u32x4_t{v.x, v.y, v.z, v.w};
+                }
+#pragma unroll
+                for (int i = 0; i < NMF; ++i) {
+                    u32x4_t bf;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        uint32_t addr;
+                        if constexpr (BITS == 4) {
+                            addr = __builtin_amdgcn_perm(qw[0][ww], lane_off, selv[i]);
+                        } else if constexpr (BITS == 2) {
+                            const uint32_t idx = (R == 1) ? ((qw[0][ww] >> (4 * i)) & 0xfu)
+                                                          : __builtin_amdgcn_ubfe(qw[0][ww], 4u * (uint32_t)(i * R + f), 4u);
+                            addr = (idx << 8) | lane_off;
+                        } else {
+                            uint32_t wv[NP];
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[pl][ww];
+                            addr = (field<BITS>(wv, i) << 8) | lane_off;
+                        }
+                        const uint32_t v = lds_ld32(addr);
+                        bf[ww] = PRE ? NT::mul_scale(v, sreg[i]) : v;
+                    }
+                    // weights are the A operand: lane (r, q) of the result = output row r, columns 4q..4q+3
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if constexpr (PRE) acc[mt][i] = Mfma<T>::run(bf, af[mt], acc[mt][i]);
+                        else run[mt][i] = Mfma<T>::run(bf, af[mt], run[mt][i]);
+                    }
+                }
+            }
+        }
+        if (t + D < nmacro) {
+            // the slot is overwritten by the DMA: every ds_read of it must have returned
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue(t + D, slot);
+        }
+        if (++slot_idx == D) { slot_idx = 0; slot = ring0; } else slot += slot_bytes;
+    }
+    if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
+    FLUTE_STAMP(2);
+
+    // ---- epilogue: the kw partial tiles of a slab are summed through LDS by ALL its waves
+    // (tile tt of the slab by wave tt % kw), then stored 8 B (16 B for split-K partials) per lane ----
+    const int c0 = q4 * 4;                                           // first of this lane's 4 columns inside a tile
+    const int colbase = unit_col0<BITS, TILEP>(slab * SU + c0 % SU) + (c0 / SU) * TILEP;
+    auto store_tile = [&](int mt, int i, const f32x4_t v) {
+        const int row = m0 + mt * 16 + r16;
+        if (row >= a.M) return;
+        const int col = colbase + i * R * TILEP;
+        if (a.splitk == 1) {
+            uint2 o;
+            o.x = (uint32_t)NT::from_float(v[0]) | ((uint32_t)NT::from_float(v[1]) << 16);
+            o.y = (uint32_t)NT::from_float(v[2]) | ((uint32_t)NT::from_float(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col) = o;
+        } else {
+            *reinterpret_cast<f32x4_t*>(a.partial + ((size_t)split * a.M + row) * a.N + col) = v;
+        }
+    };
+    if (kw == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) store_tile(mt, i, acc[mt][i]);
+    } else {
+        constexpr int NT_TILES = MT * NMF;
+        __syncthreads();                          // every wave is done with the table and its ring
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < NMF; ++i)
+                *reinterpret_cast<f32x4_t*>(smem + ((size_t)(wave * NT_TILES + mt * NMF + i) * 64 + lane) * 16) = acc[mt][i];
+        __syncthreads();
+        for (int tt = kpart; tt < NT_TILES; tt += kw) {
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw) * NT_TILES + tt) * 64 + lane) * 16);
+            for (int kp = 1; kp < kw; ++kp)
+                v += *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw + kp) * NT_TILES + tt) * 64 + lane) * 16);
+            store_tile(tt / NMF, tt % NMF, v);
+        }
+    }
+#ifdef FLUTE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);               // stores retired
+    FLUTE_STAMP(3);
+    if (lane == 0 && a.splitk == 1 && a.partial != nullptr) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.partial) + ((size_t)blockIdx.x * nw + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef FLUTE_STAMP
+}
+
+}  // namespace flute_amd

@@ -18,6 +18,8 @@ num_sms = utils.get_device_num_sms(dev)
 ws = utils.get_workspace_streamk(dev)
 lib = _lib.get()
 fails, total = [], 0
+# SELFCHECK_FAMILY=3: run every automatic / family-2 case through that kernel family instead
+FORCE_FAMILY = int(os.environ.get("SELFCHECK_FAMILY", "0"))
 
 
 def tids(bits, tile_p):
@@ -39,6 +41,8 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
         X = (torch.randn(M, K, device=dev) / 100).to(dtype)
         ref = X.float() @ What.float()
         for ovr in ovr_list:
+            if FORCE_FAMILY and ovr[0] in (-1, 2):
+                ovr = (FORCE_FAMILY,) + tuple(ovr[1:])
             lib.flute_set_overrides(*ovr)
             total += 1
             tag = f"b{bits} tp{tile_p} g{g} {str(dtype)[6:]} K{K} N{N} M{M} ovr{ovr}"

@@ -1,0 +1,61 @@
+"""Phase breakdown of the column-per-lane MFMA kernel from the FLUTE_STAMPS development build.
+
+    make -C flute_amd/csrc OBJDIR=build_stamps LIB=libflute_amd_stamps.so EXTRA=-DFLUTE_STAMPS -j
+    FLUTE_AMD_LIB=flute_amd/csrc/libflute_amd_stamps.so python tools/stamps.py
+
+Every wave writes four 100 MHz wall-clock stamps (start, prologue done, main loop done, stores
+retired) into the workspace; this prints their distribution relative to the earliest start."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from flute_amd import _lib, utils  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _lib.get()
+f16 = torch.float16
+cases = [
+    (256, 4096, 4096, (2, 1, 8, 8, 1, 4, -1)),
+    (256, 4096, 512, (2, 1, 8, 8, 1, 4, -1)),
+    (256, 4096, 4096, (2, 1, 8, 4, 1, 4, -1)),
+    (256, 11008, 4096, (2, 1, 8, 2, 1, 4, -1)),
+    (16, 4096, 4096, (2, 4, 8, 8, 1, 1, -1)),
+    (16, 4096, 1024, (2, 4, 8, 8, 1, 1, -1)),
+    (64, 4096, 4096, (2, 1, 8, 8, 1, 1, -1)),
+]
+out = []
+for (M, N, K, ovr) in cases:
+    lay = bench.Layer(M, N, K, 4, 64, f16, dev, 2)
+    lay.template_id = 16
+    lib.flute_set_overrides(*ovr)
+    plan = utils.get_plan(M, N, K, 4, 64, 16, lay.num_sms, f16)
+    nwaves = plan["grid"] * plan["waves"]
+    ws64 = lay.ws.view(torch.int64)
+    for i in range(3):
+        lay.step(i)
+    torch.cuda.synchronize()
+    ws64[: nwaves * 8].zero_()
+    torch.cuda.synchronize()
+    lay.step(0)
+    torch.cuda.synchronize()
+    st = ws64[: nwaves * 8].reshape(nwaves, 8).cpu().double()
+    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
+    t0 = st[:, 0].min()
+    us = (st - t0) / 100.0
+    q = lambda x: [round(float(v), 2) for v in (x.min(), x.median(), x.max())]  # noqa: E731
+    r = {"M": M, "N": N, "K": K, "ovr": list(ovr), "grid": plan["grid"], "waves": plan["waves"],
+         "start_us[min,med,max]": q(us[:, 0]),
+         "prologue_us": q(us[:, 1] - us[:, 0]),
+         "pro_ring_issue": q(us[:, 4] - us[:, 0]), "pro_lut": q(us[:, 5] - us[:, 4]),
+         "pro_scales": q(us[:, 6] - us[:, 5]), "pro_barrier": q(us[:, 1] - us[:, 6]),
+         "mainloop_us": q(us[:, 2] - us[:, 1]),
+         "epilogue_us": q(us[:, 3] - us[:, 2]),
+         "end_us": q(us[:, 3])}
+    out.append(r)
+    print(json.dumps(r), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/stamps.json", "w"), indent=1)

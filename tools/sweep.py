@@ -58,6 +58,42 @@ if which == "decode":
     for waves, kw in ((16, 4), (16, 2), (8, 2)):
         run(1, 4096, 4096, 2, 64, f16, 4, (0, -1, waves, kw, 1, -1, 0))
     run(1, 28672, 8192, 2, 64, f16, 4, (0, -1, 16, 1, 1, -1, 0))
+elif which == "kscale":
+    # fixed launch overhead vs per-K slope of the column-per-lane MFMA kernel
+    for kw in (8, 4, 2):
+        for K in (512, 1024, 2048, 4096, 8192, 16384):
+            if K // kw < 64:
+                continue
+            run(256, 4096, K, 4, 64, f16, 16, (2, 1, 8, kw, 1, 4, -1), steps=100, hot=True)
+    for K in (1024, 4096, 16384):
+        run(256, 4096, K, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, -1), steps=100)
+        run(64, 4096, K, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, -1), steps=100, hot=True)
+        run(16, 4096, K, 4, 64, f16, 16, (2, 4, 8, 8, 1, 1, -1), steps=100, hot=True)
+elif which == "stride":
+    # power-of-two row stride of A (L2 channel camping?) vs odd multiples of 64
+    for K in (3968, 4032, 4096, 4160, 4224, 8192, 8256):
+        run(256, 4096, K, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, -1), steps=100, hot=True)
+        run(64, 4096, K, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, -1), steps=100, hot=True)
+elif which == "tile":
+    # LDS-DMA staged MFMA kernel (family 3) against the r01 column-per-lane kernel (family 2)
+    for fam in (2, 3):
+        run(16, 4096, 4096, 4, 64, f16, 16, (fam, 4, 8, 8, 1, 1, -1))
+        run(16, 4096, 4096, 4, 64, f16, 16, (fam, 2, 8, 8, 1, 1, -1))
+        run(16, 11008, 4096, 4, 64, f16, 16, (fam, -1, -1, -1, -1, -1, -1))
+        run(16, 28672, 8192, 4, 64, f16, 16, (fam, 1, 8, 4, 1, 1, -1))
+        run(64, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 8, 1, 1, -1))
+        run(64, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 8, 1, 4, -1))
+        run(256, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 8, 1, 4, -1))
+        run(256, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 4, 1, 4, -1))
+        run(256, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 8, 1, 2, -1))
+        run(256, 4096, 4096, 4, 64, bf16, 16, (fam, 1, 8, 8, 1, 4, -1))
+        run(256, 11008, 4096, 4, 64, f16, 16, (fam, 1, 8, 2, 1, 4, -1))
+        run(256, 11008, 4096, 4, 64, f16, 16, (fam, 1, 8, 4, 1, 4, -1))
+        run(1024, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 4, 1, 4, -1))
+        run(1024, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 2, 1, 4, -1))
+        run(4096, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 1, 1, 4, -1), steps=50)
+        run(64, 8192, 8192, 3, 64, bf16, 4, (fam, -1, -1, -1, -1, -1, -1))
+        run(256, 4096, 4096, 2, 64, f16, 4, (fam, -1, -1, -1, -1, -1, -1))
 elif which == "calib":
     import time
     lib = _lib.get()
