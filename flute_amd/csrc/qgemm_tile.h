@@ -118,6 +118,11 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #define FLUTE_STAMP(i)
 #endif
 
+#ifdef FLUTE_ABLATE   // development builds only: 1 no table lookups, 2 no activation reads, 4 no refills, 8 no MFMA
+    constexpr int dbg = FLUTE_ABLATE;
+#else
+    constexpr int dbg = 0;
+#endif
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int lane = tid & 63;
@@ -274,8 +279,17 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 
     uint32_t slot = ring0;                       // slot of macro-step t
     int slot_idx = 0;
+#ifdef FLUTE_STAMPS
+    uint64_t cyc_wait = 0, cyc_loop0 = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < nmacro; ++t) {
-        dma_wait<LPS>(min(D - 1, nmacro - 1 - t));
+#ifdef FLUTE_STAMPS
+        const uint64_t cw0 = __builtin_readcyclecounter();
+#endif
+        dma_wait<LPS>((dbg & 4) ? 0 : min(D - 1, nmacro - 1 - t));
+#ifdef FLUTE_STAMPS
+        cyc_wait += __builtin_readcyclecounter() - cw0;
+#endif
 #pragma unroll
         for (int s = 0; s < R; ++s) {
             const int ks = t * R + s;
@@ -312,12 +326,15 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                 u32x4_t af[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    if ((dbg & 2) && mt > 0) { af[mt] = af[0]; continue; }
                     const uint4 v = lds_ld128(slot + (NP + s * MT + mt) * 1024 + aread);
                     af[mt] = u32x4_t{v.x, v.y, v.z, v.w};
                 }
+                // all pair lookups of the k-step are issued before the first multiply: hipcc otherwise
+                // funnels them through one register (lookup, wait, multiply, 16 times per k-step)
+                uint32_t lut[NMF][4];
 #pragma unroll
                 for (int i = 0; i < NMF; ++i) {
-                    u32x4_t bf;
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) {
                         uint32_t addr;
@@ -333,19 +350,25 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                             for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[pl][ww];
                             addr = (field<BITS>(wv, i) << 8) | lane_off;
                         }
-                        const uint32_t v = lds_ld32(addr);
-                        bf[ww] = PRE ? NT::mul_scale(v, sreg[i]) : v;
+                        lut[i][ww] = (dbg & 1) ? addr : lds_ld32(addr);
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < NMF; ++i) {
+                    u32x4_t bf;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) bf[ww] = PRE ? NT::mul_scale(lut[i][ww], sreg[i]) : lut[i][ww];
                     // weights are the A operand: lane (r, q) of the result = output row r, columns 4q..4q+3
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
+                        if (dbg & 8) { acc[mt][i][0] += __builtin_bit_cast(float, bf[0] ^ bf[1] ^ bf[2] ^ bf[3] ^ af[mt][0]); continue; }
                         if constexpr (PRE) acc[mt][i] = Mfma<T>::run(bf, af[mt], acc[mt][i]);
                         else run[mt][i] = Mfma<T>::run(bf, af[mt], run[mt][i]);
                     }
                 }
             }
         }
-        if (t + D < nmacro) {
+        if (t + D < nmacro && !(dbg & 4)) {
             // the slot is overwritten by the DMA: every ds_read of it must have returned
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue(t + D, slot);
@@ -354,6 +377,10 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     }
     if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
     FLUTE_STAMP(2);
+#ifdef FLUTE_STAMPS
+    stamp[7] = cyc_wait;                                   // shader cycles spent in dma_wait
+    stamp[4] = __builtin_readcyclecounter() - cyc_loop0;   // shader cycles of the whole main loop (replaces stamp 4)
+#endif
 
     // ---- epilogue: the kw partial tiles of a slab are summed through LDS by ALL its waves
     // (tile tt of the slab by wave tt % kw), then stored 8 B (16 B for split-K partials) per lane ----

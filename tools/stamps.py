@@ -18,14 +18,16 @@ from flute_amd import _lib, utils  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.get()
 f16 = torch.float16
+FAM = int(os.environ.get("STAMPS_FAMILY", "3"))
 cases = [
-    (256, 4096, 4096, (2, 1, 8, 8, 1, 4, -1)),
-    (256, 4096, 512, (2, 1, 8, 8, 1, 4, -1)),
-    (256, 4096, 4096, (2, 1, 8, 4, 1, 4, -1)),
-    (256, 11008, 4096, (2, 1, 8, 2, 1, 4, -1)),
-    (16, 4096, 4096, (2, 4, 8, 8, 1, 1, -1)),
-    (16, 4096, 1024, (2, 4, 8, 8, 1, 1, -1)),
-    (64, 4096, 4096, (2, 1, 8, 8, 1, 1, -1)),
+    (256, 4096, 4096, (FAM, 1, 8, 8, 1, 4, -1)),
+    (256, 4096, 512, (FAM, 1, 8, 8, 1, 4, -1)),
+    (256, 4096, 4096, (FAM, 1, 8, 4, 1, 4, -1)),
+    (256, 11008, 4096, (FAM, 1, 8, 2, 1, 4, -1)),
+    (16, 4096, 4096, (FAM, 4, 8, 8, 1, 1, -1)),
+    (16, 4096, 1024, (FAM, 4, 8, 8, 1, 1, -1)),
+    (64, 4096, 4096, (FAM, 1, 8, 8, 1, 1, -1)),
+    (4096, 4096, 4096, (FAM, 1, 8, 1, 1, 4, -1)),
 ]
 out = []
 for (M, N, K, ovr) in cases:
@@ -50,7 +52,7 @@ for (M, N, K, ovr) in cases:
     r = {"M": M, "N": N, "K": K, "ovr": list(ovr), "grid": plan["grid"], "waves": plan["waves"],
          "start_us[min,med,max]": q(us[:, 0]),
          "prologue_us": q(us[:, 1] - us[:, 0]),
-         "pro_ring_issue": q(us[:, 4] - us[:, 0]), "pro_lut": q(us[:, 5] - us[:, 4]),
+         "loop_cycles": q(st[:, 4]), "dma_wait_cycles": q(st[:, 7]), "pro_issue_lut": q(us[:, 5] - us[:, 0]),
          "pro_scales": q(us[:, 6] - us[:, 5]), "pro_barrier": q(us[:, 1] - us[:, 6]),
          "mainloop_us": q(us[:, 2] - us[:, 1]),
          "epilogue_us": q(us[:, 3] - us[:, 2]),

@@ -76,7 +76,7 @@ elif which == "stride":
         run(64, 4096, K, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, -1), steps=100, hot=True)
 elif which == "tile":
     # LDS-DMA staged MFMA kernel (family 3) against the r01 column-per-lane kernel (family 2)
-    for fam in (2, 3):
+    for fam in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (2, 3)):
         run(16, 4096, 4096, 4, 64, f16, 16, (fam, 4, 8, 8, 1, 1, -1))
         run(16, 4096, 4096, 4, 64, f16, 16, (fam, 2, 8, 8, 1, 1, -1))
         run(16, 11008, 4096, 4, 64, f16, 16, (fam, -1, -1, -1, -1, -1, -1))
