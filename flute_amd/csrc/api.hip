@@ -12,8 +12,7 @@
 #include "../../include/flute_amd.h"
 #include "kernels.h"
 #include "qgemm_decode.h"
-#include "qgemm_mfma.h"
-#include "qgemm_m16.h"
+#include "mfma.h"
 #include "qgemm_tile.h"
 
 using namespace flute_amd;
@@ -82,14 +81,11 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     int copies = g_ovr.lut_copies > 0 ? g_ovr.lut_copies : t.lut_copies;
     if (copies != 1 && copies != 8 && copies != 16 && copies != 32) copies = 32;
     p->lut_copies = copies;
-    const int lsh = ilog2(copies);
 
     const int dec_max = (bits == 3) ? 2 : 4;
     int family = (M <= dec_max) ? 0 : 2;
     if (g_ovr.family == 0 && M <= dec_max) family = 0;
-    if (g_ovr.family == 1) family = 1;
-    if (g_ovr.family == 2) family = 2;
-    if (g_ovr.family == 3) family = 3;
+    if (g_ovr.family >= 1) family = 2;            // any M may be forced through the MFMA kernel
     p->family = family;
 
     if (family == 0) {
@@ -131,8 +127,8 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->block = (unsigned)(waves * 64);
         p->lds_bytes = geo.total;
         p->lut_copies = (bits == 4) ? 64 : 32;
-    } else if (family == 2 || family == 3) {
-        // M > decode range: column-per-lane MFMA kernel.  MT 16-row tiles per wave (1 for M <= 16),
+    } else {
+        // M > decode range: MFMA kernel (qgemm_tile.h).  MT 16-row tiles per wave (1 for M <= 16),
         // R lanes share a unit: pick the smallest R whose slab x row-tile count fills the chip; the
         // rest of the parallelism is the in-workgroup K split, a grid-level split only for very
         // narrow layers.
@@ -156,11 +152,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         const int slabs = units * R / 16;
         int nw = 8;
         if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = g_ovr.waves;
-        if (family == 3) {
-            while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;
-        } else {
-            while (nw > 1 && m16_lds_bytes(bits, R, nw) > (size_t)kMaxLds) nw >>= 1;   // b=3: 16 column tiles
-        }
+        while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
@@ -183,40 +175,8 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->m_block = R; p->m_tiles = mt; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
         p->grid = (unsigned)(wgs * splitk);
         p->block = (unsigned)(nw * 64);
-        p->lds_bytes = (family == 3) ? (size_t)tile_geom(bits, R, mt, nw, kMaxLds).total : m16_lds_bytes(bits, R, nw);
-        p->lut_copies = 64;
-    } else {
-        int mt = t.tile_m / 16;
-        if (g_ovr.m_block > 0) mt = g_ovr.m_block;
-        const int mt_max = (bits == 3) ? 2 : 4;
-        if (mt > mt_max) mt = mt_max;
-        int need = 1; while (need * 16 < M && need < mt) need <<= 1;
-        mt = need;                                    // no wider than M asks for
-        if (mt != 1 && mt != 2 && mt != 4) mt = 1;
-        const int kc = (mt >= 4) ? 128 : 256;
-        const int slabs = units / 16;
-        const int mtiles = ceil_div(M, mt * 16);
-        int nw = 4;
-        while (nw > 1 && (slabs % nw)) nw >>= 1;
-        while (nw > 1 && (slabs / nw) * mtiles < num_sms) nw >>= 1;
-        if (g_ovr.waves > 0 && slabs % g_ovr.waves == 0 && g_ovr.waves <= 4) nw = g_ovr.waves;
-        const long wgs = (long)(slabs / nw) * mtiles;
-        int splitk = 1;
-        while (wgs * splitk * 2 <= (long)num_sms * t.sms_multiple && K / (splitk * 2) >= 512)
-            splitk *= 2;
-        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
-        int kps = round_up(ceil_div(K, splitk), kc);
-        splitk = ceil_div(K, kps);
-        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
-            splitk >>= 1;
-            kps = round_up(ceil_div(K, splitk), kc);
-            splitk = ceil_div(K, kps);
-        }
-        if (splitk == 1) kps = K;
-        p->m_block = mt; p->waves = nw; p->kw = 1; p->splitk = splitk; p->k_per_split = kps;
-        p->grid = (unsigned)(wgs * splitk);
-        p->block = (unsigned)(nw * 64);
-        p->lds_bytes = mfma_lds_bytes(bits, mt, lg, nw, lsh);
+        p->lds_bytes = (size_t)tile_geom(bits, R, mt, nw, kMaxLds).total;
+        p->lut_copies = 32;
     }
     p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
     if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
@@ -230,19 +190,9 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, i
         if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, pre);
         return decode_kernel_b2(dtype, tile_p, mblk, pre);
     }
-    if (family == 2) {
-        if (bits == 4) return m16_kernel_b4(dtype, tile_p, mblk, mtiles);
-        if (bits == 3) return m16_kernel_b3(dtype, tile_p, mblk, mtiles);
-        return m16_kernel_b2(dtype, tile_p, mblk, mtiles);
-    }
-    if (family == 3) {
-        if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles);
-        if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
-        return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
-    }
-    if (bits == 4) return mfma_kernel_b4(dtype, tile_p, mblk);
-    if (bits == 3) return mfma_kernel_b3(dtype, tile_p, mblk);
-    return mfma_kernel_b2(dtype, tile_p, mblk);
+    if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles);
+    if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
+    return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
 }
 
 // kernels that were already granted > 64 KB of dynamic LDS
@@ -329,7 +279,7 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.lg = ilog2(group_size);
     a.units = N / ((num_bits == 3) ? 16 : 16 / num_bits);
     a.splitk = p.splitk; a.k_per_split = p.k_per_split; a.kw = p.kw; a.m0 = 0;
-    a.lut_shift = (p.family == 1) ? ilog2(p.lut_copies) : 0;
+    a.lut_shift = 0;
     a.lds_budget = kMaxLds;
 
     QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles);

@@ -11,17 +11,10 @@ typedef void (*QGemmKernel)(const QGemmArgs);
 QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
-// r: lanes sharing one unit's words in the M<=16 kernel (1, 2, 4; b=3: 1)
-QGemmKernel m16_kernel_b4(int dtype, int tile_p, int r, int mt);
-QGemmKernel m16_kernel_b3(int dtype, int tile_p, int r, int mt);
-QGemmKernel m16_kernel_b2(int dtype, int tile_p, int r, int mt);
-// LDS-DMA staged successor of the m16 kernels (same (r, mt) combinations)
+// MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt);
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);
 QGemmKernel tile_kernel_b2(int dtype, int tile_p, int r, int mt);
-QGemmKernel mfma_kernel_b4(int dtype, int tile_p, int mt);
-QGemmKernel mfma_kernel_b3(int dtype, int tile_p, int mt);
-QGemmKernel mfma_kernel_b2(int dtype, int tile_p, int mt);
 
 int hadamard_dispatch(int dtype, const void* in, void* out, size_t numel, uint32_t h,
                       hipStream_t stream);

@@ -1,6 +1,6 @@
 // Small kernels around the hot path: split-K second pass and the native unpacker.
 #include "kernels.h"
-#include "qgemm_mfma.h"
+#include "mfma.h"
 
 namespace flute_amd {
 

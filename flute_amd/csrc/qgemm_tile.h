@@ -1,17 +1,19 @@
 // MFMA kernel for every M above the decode kernel's range, operands staged by LDS-DMA.
 //
 // gfx950 replacement for qgemm_device (flute/csrc/qgemm_kernel.hpp:617-712).  One
-// v_mfma_f32_16x16x32 consumes 16 weight columns x 32 k x 16 activation rows.  Who computes what
-// is unchanged from the first column-per-lane kernel (r01): a wave owns a SLAB of 16/R units
-// (R lanes share one unit's words and each takes J/R of its fields => J/R column tiles per
-// k-step), MT 16-row tiles of activations, and one K range of the workgroup's in-LDS K split.
+// v_mfma_f32_16x16x32 consumes 16 weight columns x 32 k x 16 activation rows.  A wave owns a SLAB
+// of 16/R units (R lanes share one unit's words and each takes J/R of its fields => J/R column
+// tiles per k-step; R > 1 gives a narrow layer 2-4x more slabs, so that it fills 256 CUs without a
+// grid-level K split and its second launch), MT 16-row tiles of activations, and one K range of
+// the workgroup's in-LDS K split.
 //
-// What changed is how the operands reach the registers.  An MFMA operand wants lane (r, q) to hold
+// The design point is how the operands reach the registers.  An MFMA operand wants lane (r, q) to hold
 // 16 B of ROW r (r = lane % 16): 64 lanes, 64 different cache lines.  The texture addresser
 // serves such a load at one lane per clock (measured, tools/ubench/ta_patterns.hip: 61.8 cycles
 // per wave-instruction, 16.6 B/clk/CU, against 17.4 cycles when 4..8 neighbouring lanes share a
-// line) and that, not MFMA, LDS or L2 bandwidth, bounded the r01 kernel (10 % of the MFMA peak
-// at M = 256, 6.6 us of load issue at M = 16).  Here every global access is line-coalesced:
+// line) and that, not MFMA, LDS or L2 bandwidth, bounded the first kernel of this round, which
+// loaded operands in that order (10 % of the MFMA peak at M = 256, 6.6 us of load issue at
+// M = 16).  Here every global access is line-coalesced:
 //   * global_load_lds_dwordx4 (LDS-DMA): lane L fetches 16 B of row L / (4R) (weights; a piece is
 //     16/R rows x R k-steps x 64 B) or row L / 4 (activations; 16 rows x 64 B), written to LDS
 //     lane-linearly; no VGPR round trip, no ds_write;
@@ -29,14 +31,14 @@
 // packbits_utils.hpp:139); bf16 applies the group scale to the fp32 MFMA result of each group run.
 #pragma once
 #include "common.h"
-#include "qgemm_mfma.h"
+#include "mfma.h"
 
 namespace flute_amd {
 
-constexpr int TILE_GB = 16;          // scale groups per staged block (wave-private table)
+constexpr int TILE_GB = 8;           // scale groups per block (one 16-B DMA granule per column)
 
 struct TileGeom {
-    int scale_bytes;   // wave-private scale table [column tile][group][16 columns]
+    int scale_bytes;   // wave-private scale blocks: 2 buffers x [column tile][16 columns][8 groups]
     int slot_bytes;    // one ring slot = one macro-step (R k-steps): NP weight + MT*R activation pieces of 1 KB
     int depth;         // ring slots per wave
     int wave_bytes;
@@ -47,10 +49,10 @@ __host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int waves
     const int J = (bits == 3) ? 16 : 16 / bits;
     const int NP = (bits == 3) ? 3 : 1;
     const int nmf = J / R;
-    const int lut = (1 << (2 * bits)) * 256;
+    const int lut = (1 << (2 * bits)) * 128;
     const int lps = NP + mt * R;
     TileGeom g;
-    g.scale_bytes = nmf * TILE_GB * 32;
+    g.scale_bytes = 2 * (nmf > 4 ? nmf : 4) * 256;
     g.slot_bytes = lps * 1024;
     int d = ((budget - lut) / waves - g.scale_bytes) / g.slot_bytes;
     if (d > 6) d = 6;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     constexpr int SU = 16 / R;                 // units per slab
     constexpr int LPS = NP + MT * R;           // DMA pieces per macro-step
     constexpr int GB = TILE_GB;
-    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 256;
+    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;     // 32 copies: one per bank of a ds_read_b32 lane group
     constexpr bool PRE = __is_same(T, F16);
     static_assert(BITS != 3 || R == 1, "3-bit fields are not byte aligned: R = 1 only");
 
@@ -180,18 +182,64 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
         xrow[mt] = A + (size_t)min(m0 + mt * 16 + arow, a.M - 1) * a.K;
     const int klim = a.K - 8;            // a lane never reads past its row (ragged last macro-step)
 
-    auto issue = [&](int t, uint32_t slot_addr) {
-        const int k0 = kb + t * (32 * R);
-        const int kq = min(k0 + qchunk * 8, klim);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dma16(qrow[pl] + (kq >> 1), slot_addr + pl * 1024);
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
+    // piece P of a macro-step starting at k0: P < NP weight plane P, else activations (k-step s, row tile mt)
+    auto issue_piece = [&](int P, int k0, uint32_t slot_addr) {
+        if (P < NP) {
+            const int kq = min(k0 + qchunk * 8, klim);
+            dma16(qrow[P] + (kq >> 1), slot_addr + P * 1024);
+        } else {
+            const int s = (P - NP) / MT, mt = (P - NP) % MT;
             const int ka = min(k0 + s * 32 + achunk * 8, klim);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) dma16(xrow[mt] + ka, slot_addr + (NP + s * MT + mt) * 1024);
+            dma16(xrow[mt] + ka, slot_addr + P * 1024);
         }
     };
+    auto issue = [&](int t, uint32_t slot_addr) {
+#pragma unroll
+        for (int P = 0; P < LPS; ++P) issue_piece(P, kb + t * (32 * R), slot_addr);
+    };
+    // ---- scale blocks: 8 groups x (NMF x 16 weight-side columns), double buffered, fetched by DMA one
+    // block ahead.  Lane L of a piece fetches the 16 B (8 groups) of column (L % 16) of tile
+    // (L / 16); LDS image [tile][column][8 groups].  Needs 16-B aligned rows of S (G % 8 == 0);
+    // other shapes stage synchronously with plain loads (sync_scales). ----
+    constexpr int SPIECES = (NMF + 3) / 4;                            // 1 KB pieces per block
+    constexpr int SBUF = (NMF > 4 ? NMF : 4) * 256;                   // bytes per buffer
+    const bool sdma = (a.G % 8) == 0;
+    const uint16_t* srow[SPIECES];
+#pragma unroll
+    for (int sp = 0; sp < SPIECES; ++sp) {
+        const int i = min(sp * 4 + q4, NMF - 1);                      // NMF < 4: the surplus lanes refetch the last tile
+        const int col = unit_col0<BITS, TILEP>(slab * SU + r16 % SU) + (i * R + r16 / SU) * TILEP;
+        srow[sp] = S + (size_t)col * a.G;
+    }
+    const int blk_last = (nsteps > 0) ? ((ke - 1) >> lg) >> 3 : -1;     // last block this wave touches
+    auto issue_scales = [&](int blk) {
+        const uint32_t dst = sc_base + (uint32_t)(blk & 1) * SBUF;
+#pragma unroll
+        for (int sp = 0; sp < SPIECES; ++sp) dma16(srow[sp] + blk * 8, dst + sp * 1024);
+    };
+    auto sync_scales = [&](int blk) {                                 // G % 8 != 0: bounds-checked, hipcc-visible loads
+        uint16_t* dst = reinterpret_cast<uint16_t*>(smem + sc_base + (uint32_t)(blk & 1) * SBUF);
+#pragma unroll
+        for (int sp = 0; sp < SPIECES; ++sp) {
+            uint16_t hv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) hv[r] = (blk * 8 + r < a.G) ? srow[sp][blk * 8 + r] : (uint16_t)0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dst[(sp * 64 + lane) * 8 + r] = hv[r];
+        }
+    };
+
+    // ---- prologue: everything the first k-step needs travels together (one memory latency):
+    // pair-table words (registers), first scale block and ring slot 0 (DMA) ----
+    constexpr int ENT = 1 << (2 * BITS);
+    constexpr int LUT_R = (ENT * 2 + 511) / 512;                      // table halves per thread at 512 threads
+    uint32_t lutv[LUT_R];
+#pragma unroll
+    for (int r = 0; r < LUT_R; ++r) {
+        const int p = tid + r * nthr;
+        lutv[r] = (p < ENT * 2) ? a.QM2[p >> 1] : 0u;
+    }
+    if (nsteps > 0 && sdma) issue_scales((kb >> lg) >> 3);
     if (nmacro > 0) issue(0, ring0);
     FLUTE_STAMP(4);
 
@@ -199,66 +247,38 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     const uint32_t qread = (uint32_t)(ul * (4 * R)) * 16;            // + ((s*4 + q4) ^ swz) * 16
     const int qswz = swz_q<R>(ul);
     const uint32_t aread = (uint32_t)(r16 * 4 + (q4 ^ swz_a(r16))) * 16;
-    uint32_t selv[NMF];
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) selv[i] = 0x0c0c0400u | ((4u + (uint32_t)(i * R + f)) << 8);   // b=4: byte j of the word
-    const uint32_t lane_off = (uint32_t)lane * 4;
+    const uint32_t lane_off = (uint32_t)(lane & 31) * 4;              // table copy of this lane
 
-    // ---- pair table (stride 256 B; 64 copies of 4 B) ----
-    {
-        constexpr int ENT = 1 << (2 * BITS);
-        for (int p = tid; p < ENT * 4; p += nthr) {
-            const uint32_t v = a.QM2[p >> 2];
-            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 2) * 256 + (p & 3) * 64);
-            const uint4 vv = make_uint4(v, v, v, v);
+    // ---- pair table: entry e at [e * 128, +128): 32 copies of its 4 bytes ----
+#pragma unroll
+    for (int r = 0; r < LUT_R; ++r) {
+        const int p = tid + r * nthr;
+        if (p < ENT * 2) {
+            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 1) * 128 + (p & 1) * 64);
+            const uint4 vv = make_uint4(lutv[r], lutv[r], lutv[r], lutv[r]);
             d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
         }
     }
+    for (int p = tid + LUT_R * nthr; p < ENT * 2; p += nthr) {        // small workgroups only
+        const uint32_t v = a.QM2[p >> 1];
+        uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 1) * 128 + (p & 1) * 64);
+        const uint4 vv = make_uint4(v, v, v, v);
+        d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
+    }
     FLUTE_STAMP(5);
-
-    // ---- wave-private scale table: block of GB groups, layout [tile][group][column] (halves);
-    // column c of tile i is the weight-side MFMA column c ----
-    int ncolB[NMF];
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) ncolB[i] = unit_col0<BITS, TILEP>(slab * SU + ul) + (i * R + f) * TILEP;
-    uint16_t* scw = reinterpret_cast<uint16_t*>(smem + sc_base);
-    auto stage_scales = [&](int gblk0) {
-        // lane (c = lane&15, o = lane>>4 < GB/8) fetches groups [gblk0 + 8o, +8) of its column
-        if (q4 < GB / 8) {
-#pragma unroll
-            for (int i = 0; i < NMF; ++i) {
-                const int g0 = gblk0 + q4 * 8;
-                const uint16_t* sp = S + (size_t)ncolB[i] * a.G + g0;
-                uint16_t hv[8];
-                if (g0 + 8 <= a.G && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0)) {
-                    const uint4 t = *reinterpret_cast<const uint4*>(sp);
-                    hv[0] = t.x & 0xffff; hv[1] = t.x >> 16; hv[2] = t.y & 0xffff; hv[3] = t.y >> 16;
-                    hv[4] = t.z & 0xffff; hv[5] = t.z >> 16; hv[6] = t.w & 0xffff; hv[7] = t.w >> 16;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) hv[r] = (g0 + r < a.G) ? sp[r] : (uint16_t)0;
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) scw[(i * GB + q4 * 8 + r) * 16 + r16] = hv[r];
-            }
-        }
-    };
-    int gblk0 = (kb >> lg) & ~7;                 // first staged group (8-aligned for vector loads)
-    if (nsteps > 0) stage_scales(gblk0);
+    if (nsteps > 0 && !sdma) sync_scales((kb >> lg) >> 3);
     FLUTE_STAMP(6);
-    // the rest of the ring (the table loads above travelled behind slot 0 only)
+    // the rest of the ring (the table words above travelled with slot 0 only)
     for (int t = 1; t < D && t < nmacro; ++t) issue(t, ring0 + (uint32_t)t * slot_bytes);
-    __syncthreads();                             // table + scales visible (only barrier before the epilogue)
+    __syncthreads();                             // table visible (only barrier before the epilogue)
     FLUTE_STAMP(1);
+    int t_sc = 0;                                // macro-step during which the next scale block was requested
 
     f32x4_t acc[MT][NMF], run[MT][NMF];
     uint32_t sreg[NMF];                          // fp16: current group's scale of weight column r16 (raw T, low half)
-    float sf[NMF][4];                            // bf16: current group's scales of the accumulator's 4 columns
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
         sreg[i] = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sf[i][e] = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             acc[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -266,15 +286,23 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
         }
     }
     int cur_group = -1;
-    auto fold_run = [&]() {
+    // bf16: fold the finished group's fp32 run into the accumulator with that group's scales (read
+    // back from the block buffer: the accumulator's 4 columns are weight-side columns 4q..4q+3)
+    auto fold_run = [&](int grp) {
+        const uint32_t sb = sc_base + (uint32_t)((grp >> 3) & 1) * SBUF + (uint32_t)(grp & 7) * 2;
 #pragma unroll
-        for (int i = 0; i < NMF; ++i)
+        for (int i = 0; i < NMF; ++i) {
+            float sf[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sf[e] = NT::to_float(*reinterpret_cast<const uint16_t*>(smem + sb + (uint32_t)(i * 16 + q4 * 4 + e) * 16));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][i][e] = __builtin_fmaf(run[mt][i][e], sf[i][e], acc[mt][i][e]);
+                for (int e = 0; e < 4; ++e) acc[mt][i][e] = __builtin_fmaf(run[mt][i][e], sf[e], acc[mt][i][e]);
                 run[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+        }
     };
 
     uint32_t slot = ring0;                       // slot of macro-step t
@@ -297,23 +325,24 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                 const int k0 = kb + ks * 32;
                 const int grp = k0 >> lg;
                 if (grp != cur_group) {
-                    if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
-                    if (grp >= gblk0 + GB) {                              // next block of scales
-                        gblk0 = grp & ~7;
-                        stage_scales(gblk0);
+                    if constexpr (!PRE) { if (cur_group >= 0) fold_run(cur_group); }
+                    const int blk = grp >> 3;
+                    if (cur_group < 0 || blk != (cur_group >> 3)) {       // entering a scale block
+                        if (sdma) {
+                            // the block was requested during macro-step t_sc, ahead of that step's refill: the
+                            // slot wait of step t covers it once t >= t_sc + D (loads retire in order); a
+                            // block entered sooner (short first block, g = 32 with R = 4) drains the queue
+                            if (cur_group >= 0 && t - t_sc < D) vm_wait<0>();
+                            if (blk < blk_last) { issue_scales(blk + 1); t_sc = t; }   // into the buffer the previous block left
+                        } else if (cur_group >= 0) {
+                            sync_scales(blk);
+                        }
                     }
                     if constexpr (PRE) {
+                        const uint32_t sb = sc_base + (uint32_t)(blk & 1) * SBUF + (uint32_t)(grp & 7) * 2;
 #pragma unroll
                         for (int i = 0; i < NMF; ++i)
-                            sreg[i] = *reinterpret_cast<const uint16_t*>(
-                                smem + sc_base + (uint32_t)((i * GB + (grp - gblk0)) * 16 + r16) * 2);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NMF; ++i) {
-                            const uint2 h = lds_ld64(sc_base + (uint32_t)((i * GB + (grp - gblk0)) * 16 + q4 * 4) * 2);
-                            sf[i][0] = NT::to_float((uint16_t)(h.x & 0xffff)); sf[i][1] = NT::to_float((uint16_t)(h.x >> 16));
-                            sf[i][2] = NT::to_float((uint16_t)(h.y & 0xffff)); sf[i][3] = NT::to_float((uint16_t)(h.y >> 16));
-                        }
+                            sreg[i] = *reinterpret_cast<const uint16_t*>(smem + sb + (uint32_t)(i * 16 + r16) * 16);
                     }
                     cur_group = grp;
                 }
@@ -330,52 +359,65 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                     const uint4 v = lds_ld128(slot + (NP + s * MT + mt) * 1024 + aread);
                     af[mt] = u32x4_t{v.x, v.y, v.z, v.w};
                 }
-                // all pair lookups of the k-step are issued before the first multiply: hipcc otherwise
-                // funnels them through one register (lookup, wait, multiply, 16 times per k-step)
-                uint32_t lut[NMF][4];
+                // Refill of this slot for macro-step t + D, spread over the k-step: a piece may be overwritten
+                // as soon as its reads have returned (the activations of k-step s now, the weights after the
+                // last k-step); one piece goes out after each column tile's MFMAs so that the wave is not
+                // parked in the texture addresser's queue for five pieces in a row
+                const bool refill = (t + D < nmacro) && !(dbg & 4);
+                const int NREF = MT + ((s == R - 1) ? NP : 0);       // constant after unrolling
+                if (refill) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the pair lookups of (up to) four column tiles are issued before their first multiply:
+                // hipcc otherwise funnels them through one register (lookup, wait, multiply, 16 times)
+                constexpr int IB = NMF < 4 ? NMF : 4;
 #pragma unroll
-                for (int i = 0; i < NMF; ++i) {
+                for (int i0 = 0; i0 < NMF; i0 += IB) {
+                    uint32_t lut[IB][4];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        uint32_t addr;
-                        if constexpr (BITS == 4) {
-                            addr = __builtin_amdgcn_perm(qw[0][ww], lane_off, selv[i]);
-                        } else if constexpr (BITS == 2) {
-                            const uint32_t idx = (R == 1) ? ((qw[0][ww] >> (4 * i)) & 0xfu)
-                                                          : __builtin_amdgcn_ubfe(qw[0][ww], 4u * (uint32_t)(i * R + f), 4u);
-                            addr = (idx << 8) | lane_off;
-                        } else {
-                            uint32_t wv[NP];
+                    for (int ii = 0; ii < IB; ++ii) {
+                        const int i = i0 + ii;
 #pragma unroll
-                            for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[pl][ww];
-                            addr = (field<BITS>(wv, i) << 8) | lane_off;
+                        for (int ww = 0; ww < 4; ++ww) {
+                            uint32_t addr;
+                            if constexpr (BITS == 4 || BITS == 2) {
+                                // v_bfe_u32 + v_lshl_or_b32 (per-lane field when R lanes share the word)
+                                const uint32_t idx = (R == 1) ? ((qw[0][ww] >> (2 * BITS * i)) & ((1u << (2 * BITS)) - 1u))
+                                                              : __builtin_amdgcn_ubfe(qw[0][ww], (uint32_t)(2 * BITS) * (uint32_t)(i * R + f),
+                                                                                      (uint32_t)(2 * BITS));
+                                addr = (idx << 7) | lane_off;
+                            } else {
+                                uint32_t wv[NP];
+#pragma unroll
+                                for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[pl][ww];
+                                addr = (field<BITS>(wv, i) << 7) | lane_off;
+                            }
+                            lut[ii][ww] = (dbg & 1) ? addr : lds_ld32(addr);
                         }
-                        lut[i][ww] = (dbg & 1) ? addr : lds_ld32(addr);
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < NMF; ++i) {
-                    u32x4_t bf;
+                    for (int ii = 0; ii < IB; ++ii) {
+                        const int i = i0 + ii;
+                        u32x4_t bf;
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) bf[ww] = PRE ? NT::mul_scale(lut[i][ww], sreg[i]) : lut[i][ww];
-                    // weights are the A operand: lane (r, q) of the result = output row r, columns 4q..4q+3
+                        for (int ww = 0; ww < 4; ++ww) bf[ww] = PRE ? NT::mul_scale(lut[ii][ww], sreg[i]) : lut[ii][ww];
+                        // weights are the A operand: lane (r, q) of the result = output row r, columns 4q..4q+3
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        if (dbg & 8) { acc[mt][i][0] += __builtin_bit_cast(float, bf[0] ^ bf[1] ^ bf[2] ^ bf[3] ^ af[mt][0]); continue; }
-                        if constexpr (PRE) acc[mt][i] = Mfma<T>::run(bf, af[mt], acc[mt][i]);
-                        else run[mt][i] = Mfma<T>::run(bf, af[mt], run[mt][i]);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (dbg & 8) { acc[mt][i][0] += __builtin_bit_cast(float, bf[0] ^ bf[1] ^ bf[2] ^ bf[3] ^ af[mt][0]); continue; }
+                            if constexpr (PRE) acc[mt][i] = Mfma<T>::run(bf, af[mt], acc[mt][i]);
+                            else run[mt][i] = Mfma<T>::run(bf, af[mt], run[mt][i]);
+                        }
+                        if (refill) {
+#pragma unroll
+                            for (int q = i; q < NREF; q += NMF)
+                                issue_piece(q < MT ? NP + s * MT + q : q - MT, kb + (t + D) * (32 * R), slot);
+                        }
                     }
                 }
             }
         }
-        if (t + D < nmacro && !(dbg & 4)) {
-            // the slot is overwritten by the DMA: every ds_read of it must have returned
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue(t + D, slot);
-        }
         if (++slot_idx == D) { slot_idx = 0; slot = ring0; } else slot += slot_bytes;
     }
-    if constexpr (!PRE) { if (cur_group >= 0) fold_run(); }
+    if constexpr (!PRE) { if (cur_group >= 0) fold_run(cur_group); }
     FLUTE_STAMP(2);
 #ifdef FLUTE_STAMPS
     stamp[7] = cyc_wait;                                   // shader cycles spent in dma_wait

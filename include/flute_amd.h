@@ -59,10 +59,9 @@ typedef struct flute_template_info {
 
 /* Launch plan chosen for a problem (host logic only, no GPU needed). */
 typedef struct flute_plan {
-    int family;          /* 0 = decode (streaming GEMV, M<=4), 2 = column-per-lane MFMA (M>4),
-                            1 = first-generation LDS-staged MFMA kernel (override only) */
-    int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit);
-                            family 1: 16-row tiles per wave */
+    int family;          /* 0 = decode (streaming GEMV, M<=4; 3 bits: M<=2), 2 = MFMA kernel with
+                            LDS-DMA staged operands (every larger M) */
+    int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int waves;           /* waves per workgroup */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
@@ -111,7 +110,7 @@ int flute_num_templates(int num_bits);
 int flute_get_template_info(int num_bits, int template_id, flute_template_info* out);
 
 /* Tuning overrides for the offline tuner / benchmarks; -1 = automatic.
- * family: 0 decode, 1 MFMA.  prescale: 1 = decode kernel rounds lut*scale per
+ * family: 0 decode, 2 (or any value >= 1) MFMA.  prescale: 1 = decode kernel rounds lut*scale per
  * pair (fp16 only; the reference's exact arithmetic), 0/-1 = scale applied per
  * 8-k run in fp32.  For family 2, m_block overrides R and lut_copies (1/2/4) overrides the
  * row tiles per wave.  Process-global, not thread-safe. */

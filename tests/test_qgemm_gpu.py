@@ -186,7 +186,7 @@ def test_mfma_family_for_small_M(env):
         try:
             for M in (1, 7):
                 X = (torch.randn(M, K) / 100).to(dtype)
-                lib.flute_set_overrides(1, -1, -1, -1, -1, -1, -1)
+                lib.flute_set_overrides(2, -1, -1, -1, -1, -1, -1)
                 D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
                 assert rel_err(D, X.float() @ What) < tol_of(dtype)
         finally:

@@ -18,7 +18,7 @@ num_sms = utils.get_device_num_sms(dev)
 ws = utils.get_workspace_streamk(dev)
 lib = _lib.get()
 fails, total = [], 0
-# SELFCHECK_FAMILY=3: run every automatic / family-2 case through that kernel family instead
+# SELFCHECK_FAMILY=2: run every automatic case (also M <= 4) through the MFMA kernel
 FORCE_FAMILY = int(os.environ.get("SELFCHECK_FAMILY", "0"))
 
 
@@ -41,7 +41,7 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
         X = (torch.randn(M, K, device=dev) / 100).to(dtype)
         ref = X.float() @ What.float()
         for ovr in ovr_list:
-            if FORCE_FAMILY and ovr[0] in (-1, 2):
+            if FORCE_FAMILY and ovr[0] == -1:
                 ovr = (FORCE_FAMILY,) + tuple(ovr[1:])
             lib.flute_set_overrides(*ovr)
             total += 1
@@ -84,7 +84,7 @@ for bits, tile_p in [(4, 32), (4, 64), (2, 32), (2, 64), (3, 32)]:
         case(bits, tile_p, 64, dtype, 1024, 2 * blk, [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 130], [AUTO, (-1, -1, -1, -1, -1, -1, 1)])
     case(bits, tile_p, 128, torch.float16, 4608, blk, [1, 4, 8, 16, 48, 70],
          [AUTO, (-1, -1, -1, 1, 1, 32, 0), (-1, -1, -1, 2, 2, 8, 1), (-1, -1, 4, 4, 1, 1, 0), (-1, -1, 16, 8, 1, 1, 1),
-          (1, -1, -1, -1, 2, 32, -1), (1, 1, 1, -1, 1, 32, -1), (1, 2, 2, -1, 4, 32, -1),
+          (2, 1, 2, 2, 2, -1, -1), (2, 1, 1, 1, 1, 1, -1), (2, 2, 2, 1, 4, 2, -1),
           (2, 1, -1, -1, -1, -1, -1), (2, 2, 8, 4, 2, -1, -1), (2, 4, 4, 1, 1, -1, -1), (2, 4, 8, 8, 1, -1, -1),
           (2, 1, -1, -1, -1, 4, -1), (2, 2, 8, 2, 1, 2, -1), (2, 1, 4, 4, 2, 2, -1), (2, 2, -1, -1, -1, 4, -1)])
     case(bits, tile_p, 32, torch.float16, 256, blk, [1, 7, 20], [AUTO])
