@@ -25,6 +25,7 @@ Overrides g_ovr = {-1, -1, -1, -1, -1, -1, -1};
 constexpr int kMaxLds = 160 * 1024;
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
@@ -92,7 +93,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         int mb = 1; while (mb < M) mb <<= 1;
         if (g_ovr.m_block > 0 && g_ovr.m_block >= M && g_ovr.m_block <= dec_max) mb = g_ovr.m_block;
         int waves = t.threads / 64;
-        if (g_ovr.waves > 0) waves = g_ovr.waves;
+        if (g_ovr.waves > 0) waves = floor_pow2(g_ovr.waves);      // the kernels shift by log2(waves), log2(kw)
         if (waves > dec_max_threads(bits, mb) / 64) waves = dec_max_threads(bits, mb) / 64;
         if (waves < 1) waves = 1;
         // K split so that the chip holds >= num_sms * mult workgroups' worth of waves; every
@@ -102,7 +103,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
         int kw = f < waves ? f : waves;
         int splitk = f / kw;
-        if (g_ovr.kw > 0) kw = g_ovr.kw;
+        if (g_ovr.kw > 0) kw = floor_pow2(g_ovr.kw);
         if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
         if (kw > waves) kw = waves;
         while (waves % kw) kw >>= 1;
@@ -151,13 +152,13 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         if (g_ovr.m_block > 0 && combo_ok(g_ovr.m_block, mt)) R = g_ovr.m_block;
         const int slabs = units * R / 16;
         int nw = 8;
-        if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = g_ovr.waves;
+        if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = floor_pow2(g_ovr.waves);
         while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
         while (kw > 1 && (long)slabs * mtiles / (nw / kw) >= 2L * num_sms * t.sms_multiple && K / kw < 1024) kw >>= 1;
-        if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = g_ovr.kw;
+        if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = floor_pow2(g_ovr.kw);
         while (nw % kw) kw >>= 1;
         while (slabs % (nw / kw)) kw <<= 1;
         const long wgs = (long)slabs / (nw / kw) * mtiles;
@@ -281,6 +282,19 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.splitk = p.splitk; a.k_per_split = p.k_per_split; a.kw = p.kw; a.m0 = 0;
     a.lut_shift = 0;
     a.lds_budget = kMaxLds;
+    a.lkw = ilog2(p.kw);
+    for (int i = 0; i < 10; ++i) a.geo[i] = 0;
+    if (p.family == 0) {
+        const DecodeGeom g = decode_geom(num_bits, p.m_block, a.lg, p.waves, p.kw, p.k_per_split, kMaxLds);
+        a.geo[0] = g.kc; a.geo[1] = g.nbuf; a.geo[2] = g.gcap; a.geo[3] = ilog2(g.upw);
+        a.geo[4] = (int)g.x_off; a.geo[5] = (int)g.s_off; a.geo[6] = (int)g.red_off; a.geo[7] = ilog2(g.kc);
+        const int ngroups = a.units / g.upw, nwg = (int)p.grid / p.splitk;
+        a.geo[8] = ngroups / nwg; a.geo[9] = ngroups % nwg;
+    } else {
+        const TileGeom g = tile_geom(num_bits, p.m_block, p.m_tiles, p.waves, kMaxLds);
+        a.geo[0] = g.depth; a.geo[1] = g.scale_bytes; a.geo[2] = g.slot_bytes; a.geo[3] = g.wave_bytes;
+        a.geo[4] = ceil_div(M, p.m_tiles * 16);
+    }
 
     QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles);
     if (!fn) return FLUTE_ERR_TEMPLATE_ID;

@@ -137,6 +137,12 @@ struct QGemmArgs {
     int m0;                 // first row of A/D this launch handles (M-blocking of the decode kernel)
     int lut_shift;          // log2(LDS replicas of the pair table): 5, 4, 3 or 0 (MFMA kernel)
     int lds_budget;         // dynamic LDS the launch was sized for (decode kernel carve)
+    int lkw;                // log2(kw) (kw and the waves per workgroup are powers of two)
+    // launch geometry computed once by the host planner (integer divisions cost the kernels'
+    // prologue ~0.1 us each).  decode: kc, nbuf, gcap, log2(upw), x_off, s_off, red_off, log2(kc),
+    // unit groups / workgroups (quotient, remainder); MFMA: depth, scale_bytes, slot_bytes,
+    // wave_bytes, row-tile count
+    int geo[10];
 };
 
 // ---- LDS access by absolute byte address -----------------------------------------
@@ -190,6 +196,11 @@ __device__ __forceinline__ ring16_t ring_load16_nt(const void* p) {
 #endif
     return v;
 }
+__device__ __forceinline__ uint32_t ring_load4(const void* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 // wait until at most N vector-memory ops are outstanding; the listed registers become
 // valid here (the "+v" ties every later use of them behind the wait)
 template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a) {
@@ -200,6 +211,10 @@ template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a, ring16_t
 }
 template <int N> __device__ __forceinline__ void ring_wait(ring16_t& a, ring16_t& b, ring16_t& c) {
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void ring_wait4(uint32_t& a, uint32_t& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -27,6 +27,8 @@
 //     would otherwise be too small, across workgroups (fp32 slabs + reduce pass);
 //   * lane reduction with DPP row ops + v_readlane, not ds_bpermute.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace flute_amd {
@@ -118,6 +120,14 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     constexpr int LSH = (CK == 2) ? 2 : 3; // lanes per line = 8 / CK
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FLUTE_STAMPS   // development build: 100 MHz wall-clock stamps of the FIRST visit, per wave, into the workspace
+    uint64_t stamp[8];
+    for (int i = 0; i < 8; ++i) stamp[i] = 0;
+    stamp[0] = wall_clock64();
+#define FLUTE_DSTAMP(i) if (stamp[i] == 0) stamp[i] = wall_clock64()
+#else
+#define FLUTE_DSTAMP(i)
+#endif
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -127,17 +137,24 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = nthr >> 6;
     const int kw = a.kw;
-    const int ul = wave / kw;
-    const int kpart = wave - ul * kw;
+#ifdef FLUTE_STAMPS
+    asm volatile("" :: "s"(kw));             // the kernel arguments have arrived
+    stamp[7] = wall_clock64();
+#endif
+    const int lkw = a.lkw;
+    const int ul = wave >> lkw;
+    const int kpart = wave & (kw - 1);
     const int lg = a.lg;
 
-    const DecodeGeom geo = decode_geom(BITS, MB, lg, nw, kw, a.k_per_split, a.lds_budget);
+    // LDS carve of decode_geom(), evaluated by the host planner (no integer division in this prologue)
+    struct { int kc, nbuf, gcap, upw, x_off, s_off; } geo = {a.geo[0], a.geo[1], a.geo[2], 1 << a.geo[3], a.geo[4], a.geo[5]};
     const int KC = geo.kc;
     const int upw = geo.upw;
     const int ncols = upw * J;
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + geo.x_off);
-    uint32_t* ss = reinterpret_cast<uint32_t*>(smem + geo.s_off);
-    float* red = reinterpret_cast<float*>(smem + geo.red_off);
+    const int lncols = a.geo[3] + ((J == 4) ? 2 : (J == 8 ? 3 : 4));
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + a.geo[4]);
+    uint32_t* ss = reinterpret_cast<uint32_t*>(smem + a.geo[5]);
+    float* red = reinterpret_cast<float*>(smem + a.geo[6]);
     const int gstride = (geo.gcap + 7) & ~7;                  // words per column in the scale stage
     const size_t ss_buf_words = (size_t)gstride * ncols;
 
@@ -147,10 +164,13 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     const uint32_t lds0 = lds_base_of(smem);
     if (lds0 != 0) __builtin_trap();
 
-    const int split = blockIdx.x % a.splitk;
-    const int wg = blockIdx.x / a.splitk;
-    const int nwg = gridDim.x / a.splitk;
-    const int ngroups = a.units / upw;
+    int split = 0, wg = blockIdx.x, nwg = gridDim.x;
+    if (a.splitk > 1) {                                        // rare (very narrow layers)
+        split = blockIdx.x % a.splitk;
+        wg = blockIdx.x / a.splitk;
+        nwg = gridDim.x / a.splitk;
+    }
+    const int ngroups = a.units >> a.geo[3];
     const int kbeg = split * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
 
@@ -160,15 +180,26 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     constexpr int LUT_PCS = (BITS == 3) ? 2 : 4;             // 64-B pieces per entry
     constexpr bool BIG_WG = dec_max_threads(BITS, MB) == 1024;   // 128-VGPR variants: keep the prologue lean
     constexpr int LUT_R = BIG_WG ? 2 : 4;                     // table pieces per thread held in registers
+    // ASYNC = loads hidden from hipcc (inline asm) and waited for with ONE counted s_waitcnt after the
+    // first weight-ring slots have been issued behind them: the prologue's staging data then returns
+    // FIRST (loads retire in order) and the first ring slot is consumed while the rest of the weights
+    // are still streaming.  Every staging load is unconditional (clamped address): its register must
+    // not be read, copied or merged before the wait.
     uint32_t lut_v0[LUT_R], lut_v1[LUT_R];
-    auto lut_issue = [&]() {
+    auto lut_issue = [&](auto async_tag) {
+        constexpr bool ASYNC = decltype(async_tag)::value;
 #pragma unroll
         for (int r = 0; r < LUT_R; ++r) {
-            const int p = tid + r * nthr;
-            if (p < LUT_ENT * LUT_PCS) {
-                const int e = p / LUT_PCS;
-                if constexpr (BITS == 2) { lut_v0[r] = a.QM2[e & 15]; lut_v1[r] = a.QM2[e >> 4]; }
-                else { lut_v0[r] = a.QM2[e]; lut_v1[r] = lut_v0[r]; }
+            const int e = min(tid + r * nthr, LUT_ENT * LUT_PCS - 1) / LUT_PCS;
+            const uint32_t* s0 = a.QM2 + ((BITS == 2) ? (e & 15) : e);
+            const uint32_t* s1 = a.QM2 + ((BITS == 2) ? (e >> 4) : e);
+            lut_v1[r] = 0;
+            if constexpr (ASYNC) {
+                lut_v0[r] = ring_load4(s0);
+                if constexpr (BITS == 2) lut_v1[r] = ring_load4(s1);
+            } else {
+                lut_v0[r] = *s0;
+                if constexpr (BITS == 2) lut_v1[r] = *s1;
             }
         }
     };
@@ -179,7 +210,8 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             if (p < LUT_ENT * LUT_PCS) {
                 const int e = p / LUT_PCS;
                 uint4* d = reinterpret_cast<uint4*>(smem + (size_t)e * (LUT_PCS * 64) + (p % LUT_PCS) * 64);
-                const uint4 vv = make_uint4(lut_v0[r], lut_v1[r], lut_v0[r], lut_v1[r]);
+                const uint32_t v1 = (BITS == 2) ? lut_v1[r] : lut_v0[r];
+                const uint4 vv = make_uint4(lut_v0[r], v1, lut_v0[r], v1);
                 d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
             }
         }
@@ -193,29 +225,27 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
         }
     };
-    bool lut_ready = false;
     // per-lane low address byte(s) of a lookup
     const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8 : (BITS == 4 ? (uint32_t)lane * 4
                                                                                   : (uint32_t)(lane & 31) * 4);
 
     const size_t row_words = (size_t)(a.K >> 1);
-    int staged_chunk = -1;               // chunk whose activations sit in LDS (nbuf == 1 case)
-
     // ---- the wave's work is a flat list of VISITS (unit group, K chunk); its weights form ONE
     // continuous stream through a U-slot register ring: a refill that runs past the end of a
     // visit fetches the head of the next one, so the ring only drains when the kernel ends ----
-    const int nchunks = (kend - kbeg + KC - 1) / KC;
-    const int nug = (wg < ngroups) ? (ngroups - wg + nwg - 1) / nwg : 0;
+    // chunked staging (nbuf == 2) uses power-of-two chunks
+    const int nchunks = (geo.nbuf == 1) ? 1 : (kend - kbeg + KC - 1) >> a.geo[7];
+    const int nug = a.geo[8] + (wg < a.geo[9] ? 1 : 0);        // unit groups wg, wg + nwg, ... < ngroups
     const int nvisits = nug * nchunks;
     struct Visit { int ug, c, kc0, kc_len, l0, myL, nIp, kbase, lnmax; };
-    auto visit_of = [&](int v) -> Visit {
+    auto visit_of = [&](int ugi, int c_) -> Visit {            // visit = (ugi-th unit group of this workgroup, chunk c_)
         Visit t;
-        t.ug = wg + (v / nchunks) * nwg;
-        t.c = v - (v / nchunks) * nchunks;
+        t.ug = wg + ugi * nwg;
+        t.c = c_;
         t.kc0 = kbeg + t.c * KC;
         t.kc_len = min(KC, kend - t.kc0);
         const int Lc = t.kc_len >> 6;                                        // 64-k lines in the chunk
-        const int Lw = (((Lc + kw - 1) / kw) + LPS - 1) & ~(LPS - 1);         // lines per wave
+        const int Lw = (((Lc + kw - 1) >> lkw) + LPS - 1) & ~(LPS - 1);      // lines per wave
         t.l0 = kpart * Lw;
         t.myL = max(0, min(Lw, Lc - t.l0));
         const int nI = (t.myL + LPS - 1) / LPS;
@@ -234,11 +264,14 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
     ring16_t q[U][NP][CK];
     constexpr int RING_SLOT = NP * CK;               // loads per slot
     Visit cur, nxt;
+    int vis_ugi = 0;                                 // unit-group ordinal of the current visit
     const uint32_t* crow[NP];
     const uint32_t* nrow[NP];
     auto load_next_desc = [&](int v) {               // descriptor of visit v+1 (or a clamp onto cur's last line)
         if (v + 1 < nvisits) {
-            nxt = visit_of(v + 1);
+            int nc = cur.c + 1, nu = vis_ugi;
+            if (nc == nchunks) { nc = 0; ++nu; }
+            nxt = visit_of(nu, nc);
             rows_of(nxt.ug, nrow);
         } else {
             nxt = cur;
@@ -263,12 +296,138 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             for (int ck = 0; ck < CK; ++ck) q[i][pl][ck] = ring_load16_nt(base + (kk >> 1) + ck * 4);
         }
     };
-    if (nvisits > 0) {
-        cur = visit_of(0);
-        rows_of(cur.ug, crow);
-        load_next_desc(0);
+    // Staging of one visit's activations and scales, split into "issue the loads" (first XP 16-B pieces
+    // of the activations and one 8-group piece of scales per thread, kept in registers) and "write LDS"
+    // (+ plain load-and-store passes for whatever exceeds those registers).
+    constexpr int XP = BIG_WG ? 1 : 4;                    // 16-B activation pieces per thread (registers)
+    int staged_chunk = -1;               // chunk whose activations sit in LDS (nbuf == 1 case)
+    ring16_t xv[XP], sv;
+    struct StageCtx { int ug, c, kc0, kc_len, g0c, gcnt, xpieces, spieces, s_cidx, s_gp; bool s_fast; };
+    StageCtx sc;
+    auto scale_src = [&](int pidx, int& cidx, int& gp) -> const uint16_t* {
+        // consecutive threads take consecutive columns: conflict-free LDS writes below
+        const int gpi = pidx >> lncols;                 // ncols = upw * J is a power of two
+        cidx = pidx - gpi * ncols;
+        gp = gpi * 8;
+        const int ulc = cidx / J;
+        const int j = cidx - ulc * J;
+        const int n = unit_col0<BITS, TILEP>(sc.ug * upw + ulc) + j * TILEP;
+        return S + (size_t)n * a.G + sc.g0c + gp;
+    };
+    auto stage_issue = [&](const Visit& vis, auto async_tag) {
+        constexpr bool ASYNC = decltype(async_tag)::value;
+        sc.ug = vis.ug; sc.c = vis.c; sc.kc0 = vis.kc0; sc.kc_len = vis.kc_len;
+        sc.g0c = vis.kc0 >> lg;
+        sc.gcnt = ((vis.kc0 + vis.kc_len - 1) >> lg) - sc.g0c + 1;
+        const bool stage_x = (geo.nbuf == 2) || (staged_chunk != vis.c);
+        sc.xpieces = stage_x ? MB * (KC / 8) : 0;
+        sc.spieces = ncols * ((sc.gcnt + 7) >> 3);
+        FLUTE_DSTAMP(4);
+        if (sc.xpieces > 0) {                                     // workgroup-uniform
 #pragma unroll
-        for (int i = 0; i < U; ++i) ring_load(i, i);
+            for (int r = 0; r < XP; ++r) {
+                const int pidx = min(r * nthr + tid, sc.xpieces - 1);
+                const int m = (MB == 1) ? 0 : pidx / (KC / 8);
+                const int kk = min((pidx - m * (KC / 8)) * 8, sc.kc_len - 8);
+                const uint16_t* src = A + (size_t)min(a.m0 + m, a.M - 1) * a.K + sc.kc0 + kk;
+                if constexpr (ASYNC) xv[r] = ring_load16(src);
+                else xv[r] = *reinterpret_cast<const ring16_t*>(src);
+            }
+        }
+        {
+            const uint16_t* sp0 = scale_src(min(tid, sc.spieces - 1), sc.s_cidx, sc.s_gp);
+            // full, 16-B aligned run of 8 groups: one vector load; anything else is read element-wise at commit
+            sc.s_fast = (sc.s_gp + 8 <= sc.gcnt) && ((reinterpret_cast<uintptr_t>(sp0) & 15) == 0);
+            const uint16_t* src = sc.s_fast ? sp0 : S;
+            if constexpr (ASYNC) sv = ring_load16(src);
+            else sv = *reinterpret_cast<const ring16_t*>(src);
+        }
+    };
+    auto stage_commit = [&]() {
+        const int buf = (geo.nbuf == 2) ? (sc.c & 1) : 0;
+        uint16_t* xsb = xs + (size_t)buf * MB * KC;
+        uint32_t* ssb = ss + (size_t)buf * ss_buf_words;
+        const int kc0 = sc.kc0, kc_len = sc.kc_len, gcnt = sc.gcnt;
+        auto scale_load_slow = [&](const uint16_t* sp, int gp) -> uint4 {
+            uint16_t h[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) h[r] = (gp + r < gcnt) ? sp[r] : (uint16_t)0;
+            return make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16),
+                              h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
+        };
+        auto scale_load = [&](const uint16_t* sp, int gp) -> uint4 {
+            if (gp + 8 <= gcnt && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0))
+                return *reinterpret_cast<const uint4*>(sp);
+            return scale_load_slow(sp, gp);
+        };
+        // scales live in LDS as [column][gstride] 32-bit words (fp32, or raw T for PRE)
+        auto scale_store = [&](uint4 t, int cidx, int gp) {
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+            uint32_t o[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint16_t h = (uint16_t)((r & 1) ? (w[r >> 1] >> 16) : (w[r >> 1] & 0xffff));
+                o[r] = PRE ? (uint32_t)h : __builtin_bit_cast(uint32_t, NT::to_float(h));
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (gp + r < gstride) ssb[(size_t)(gp + r) * ncols + cidx] = o[r];
+        };
+        FLUTE_DSTAMP(5);
+        FLUTE_DSTAMP(6);
+#pragma unroll
+        for (int r = 0; r < XP; ++r) {
+            const int pidx = r * nthr + tid;
+            if (pidx < sc.xpieces) {
+                const int m = (MB == 1) ? 0 : pidx / (KC / 8);
+                const int kk = (pidx - m * (KC / 8)) * 8;
+                const uint4 v = (kk < kc_len) ? make_uint4(xv[r].x, xv[r].y, xv[r].z, xv[r].w) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
+            }
+        }
+        if (tid < sc.spieces) {
+            int cidx, gp;
+            const uint16_t* sp0 = scale_src(tid, cidx, gp);
+            const uint4 t = sc.s_fast ? make_uint4(sv.x, sv.y, sv.z, sv.w) : scale_load_slow(sp0, gp);
+            scale_store(t, cidx, gp);
+        }
+        // leftovers (large MB*K or many columns): plain load-then-store passes
+        for (int pidx = XP * nthr + tid; pidx < sc.xpieces; pidx += nthr) {
+            const int m = (MB == 1) ? 0 : pidx / (KC / 8);
+            const int kk = (pidx - m * (KC / 8)) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kk < kc_len)
+                v = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + kc0 + kk);
+            *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
+        }
+        for (int pidx = nthr + tid; pidx < sc.spieces; pidx += nthr) {
+            int cidx, gp;
+            const uint16_t* sp = scale_src(pidx, cidx, gp);
+            scale_store(scale_load(sp, gp), cidx, gp);
+        }
+        staged_chunk = sc.c;
+    };
+    if (nvisits > 0) {
+        // Issue order = return order: table words, visit 0's activations and scales, then the first U
+        // ring slots.  One counted wait (U ring slots may still be in flight) releases the staging
+        // data; the wave then writes LDS while its weights are still arriving.
+        cur = visit_of(0, 0);
+        rows_of(cur.ug, crow);
+        lut_issue(std::true_type{});
+        stage_issue(cur, std::true_type{});
+#pragma unroll
+        for (int i = 0; i < U; ++i) ring_load(i, i);     // slots < cur.nIp: needs no successor descriptor
+        load_next_desc(0);
+        {
+            constexpr int NY = U * RING_SLOT;            // loads issued after the staging loads
+#pragma unroll
+            for (int r = 0; r < LUT_R; ++r) ring_wait4<NY>(lut_v0[r], lut_v1[r]);
+#pragma unroll
+            for (int r = 0; r < XP; ++r) ring_wait<NY>(xv[r]);
+            ring_wait<NY>(sv);
+        }
+        lut_commit();
+        stage_commit();
     }
 
     float acc[J][MB];
@@ -292,98 +451,13 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             uint16_t* xsb = xs + (size_t)buf * MB * KC;
             uint32_t* ssb = ss + (size_t)buf * ss_buf_words;
 
-            // ---- stage table / activations / scales: every global load is issued before the
-            // first LDS write, so the prologue costs one memory latency, not three ----
-            const bool stage_x = (geo.nbuf == 2) || (staged_chunk != c);
-            constexpr int XP = BIG_WG ? 1 : 4;                    // 16-B activation pieces per thread (registers)
-            const int xpieces = stage_x ? MB * (KC / 8) : 0;
-            const int spieces_per_col = (gcnt + 7) >> 3;
-            const int spieces = ncols * spieces_per_col;
-            uint4 xv[XP];
-            uint4 sv = make_uint4(0, 0, 0, 0);
-            if (!lut_ready) lut_issue();
-#pragma unroll
-            for (int r = 0; r < XP; ++r) {
-                const int p = r * nthr + tid;
-                xv[r] = make_uint4(0, 0, 0, 0);
-                if (p < xpieces) {
-                    const int m = p / (KC / 8);
-                    const int kk = (p - m * (KC / 8)) * 8;
-                    if (kk < kc_len) {
-                        const int row = min(a.m0 + m, a.M - 1);
-                        xv[r] = *reinterpret_cast<const uint4*>(A + (size_t)row * a.K + kc0 + kk);
-                    }
-                }
-            }
-            auto scale_src = [&](int p, int& cidx, int& gp) -> const uint16_t* {
-                // consecutive threads take consecutive columns: conflict-free LDS writes below
-                const int gpi = p / ncols;
-                cidx = p - gpi * ncols;
-                gp = gpi * 8;
-                const int ulc = cidx / J;
-                const int j = cidx - ulc * J;
-                const int n = unit_col0<BITS, TILEP>(ug * upw + ulc) + j * TILEP;
-                return S + (size_t)n * a.G + g0c + gp;
-            };
-            auto scale_load = [&](const uint16_t* sp, int gp) -> uint4 {
-                if (gp + 8 <= gcnt && ((reinterpret_cast<uintptr_t>(sp) & 15) == 0))
-                    return *reinterpret_cast<const uint4*>(sp);
-                uint16_t h[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) h[r] = (gp + r < gcnt) ? sp[r] : (uint16_t)0;
-                return make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16),
-                                  h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
-            };
-            // scales live in LDS as [column][gstride] 32-bit words (fp32, or raw T for PRE)
-            auto scale_store = [&](uint4 t, int cidx, int gp) {
-                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-                uint32_t o[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint16_t h = (uint16_t)((r & 1) ? (w[r >> 1] >> 16) : (w[r >> 1] & 0xffff));
-                    o[r] = PRE ? (uint32_t)h : __builtin_bit_cast(uint32_t, NT::to_float(h));
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (gp + r < gstride) ssb[(size_t)(gp + r) * ncols + cidx] = o[r];
-            };
-            int s_cidx = 0, s_gp = 0;
-            if (tid < spieces) {
-                const uint16_t* sp0 = scale_src(tid, s_cidx, s_gp);   // sets s_cidx / s_gp first
-                sv = scale_load(sp0, s_gp);
-            }
-
-            if (!lut_ready) { lut_commit(); lut_ready = true; }
-#pragma unroll
-            for (int r = 0; r < XP; ++r) {
-                const int p = r * nthr + tid;
-                if (p < xpieces) {
-                    const int m = p / (KC / 8);
-                    const int kk = (p - m * (KC / 8)) * 8;
-                    *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = xv[r];
-                }
-            }
-            if (tid < spieces) scale_store(sv, s_cidx, s_gp);
-            // leftovers (large MB*K or many columns): plain load-then-store passes
-            for (int p = XP * nthr + tid; p < xpieces; p += nthr) {
-                const int m = p / (KC / 8);
-                const int kk = (p - m * (KC / 8)) * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (kk < kc_len)
-                    v = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + kc0 + kk);
-                *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
-            }
-            for (int p = nthr + tid; p < spieces; p += nthr) {
-                int cidx, gp;
-                const uint16_t* sp = scale_src(p, cidx, gp);
-                scale_store(scale_load(sp, gp), cidx, gp);
-            }
-            staged_chunk = c;
+            if (v > 0) { stage_issue(cur, std::false_type{}); stage_commit(); }   // visit 0: staged by the prologue
             __syncthreads();
             // Every load issued so far has landed (in-order retirement: the staging loads above
             // were consumed).  Tell hipcc so: otherwise it guards registers last written by a
             // staging load with s_waitcnt vmcnt(0) at the loop header and drains the ring.
             __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), lgkmcnt/expcnt untouched
+            FLUTE_DSTAMP(1);
 
             // ---- stream the lines: consume slot i, then refill it U slots ahead ----
             for (int it = 0; it < cur.nIp; it += U) {
@@ -487,11 +561,13 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             }
         }
         // advance the stream descriptors (the ring already holds the next visit's first U slots)
+        if (cur.c == nchunks - 1) ++vis_ugi;
         cur = nxt;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) crow[pl] = nrow[pl];
         load_next_desc(v + 1);
         if (c != nchunks - 1) continue;
+        FLUTE_DSTAMP(2);
 
         // ---- lanes -> wave (DPP) -> kw waves (LDS) -> output ----
 #pragma unroll
@@ -528,6 +604,15 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             else ring_wait<0>(q[i][0][0]);
         }
     }
+#ifdef FLUTE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    stamp[3] = wall_clock64();
+    if (lane == 0 && a.splitk == 1 && a.partial != nullptr) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.partial) + ((size_t)blockIdx.x * nw + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef FLUTE_DSTAMP
 }
 
 }  // namespace flute_amd

@@ -133,16 +133,18 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = nthr >> 6;
     const int kw = a.kw;
-    const int ns = nw / kw;
-    const int sl = wave / kw;
-    const int kpart = wave - sl * kw;
+    const int lkw = a.lkw;                     // kw and the waves per workgroup are powers of two
+    const int ns = nw >> lkw;
+    const int sl = wave >> lkw;
+    const int kpart = wave & (kw - 1);
     const int lg = a.lg;
 
-    int bid = blockIdx.x;
-    const int split = bid % a.splitk;  bid /= a.splitk;
-    const int mtiles = (a.M + MT * 16 - 1) / (MT * 16);
-    const int mtile = bid % mtiles;
-    const int sg = bid / mtiles;
+    // block -> (slab group, row tile, K split); the common single-tile / unsplit cases divide nothing
+    int bid = blockIdx.x, split = 0, mtile = 0;
+    if (a.splitk > 1) { split = bid % a.splitk; bid /= a.splitk; }
+    const int mtiles = a.geo[4];
+    if (mtiles > 1) { mtile = bid % mtiles; bid /= mtiles; }
+    const int sg = bid;
     const int m0 = mtile * (MT * 16);
     const int slab = sg * ns + sl;
     // MFMA role of this lane on the weight side: column r16 of every column tile =
@@ -151,17 +153,17 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     const int f = r16 / SU;
     const int kbeg = split * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
-    const int kpw = (((kend - kbeg + kw - 1) / kw) + 32 * R - 1) / (32 * R) * (32 * R);
+    const int kpw = (((kend - kbeg + kw - 1) >> lkw) + 32 * R - 1) / (32 * R) * (32 * R);
     const int kb = min(kend, kbeg + kpart * kpw);
     const int ke = min(kend, kb + kpw);
     const int nsteps = (ke - kb) >> 5;
     const int nmacro = (nsteps + R - 1) / R;
 
-    const TileGeom geo = tile_geom(BITS, R, MT, nw, a.lds_budget);
-    const int D = geo.depth;
-    const uint32_t sc_base = LUT_BYTES + (uint32_t)wave * geo.wave_bytes;
-    const uint32_t ring0 = sc_base + geo.scale_bytes;
-    const uint32_t slot_bytes = geo.slot_bytes;
+    // LDS carve of tile_geom(), evaluated by the host planner
+    const int D = a.geo[0];
+    const uint32_t sc_base = LUT_BYTES + (uint32_t)wave * (uint32_t)a.geo[3];
+    const uint32_t ring0 = sc_base + (uint32_t)a.geo[1];
+    const uint32_t slot_bytes = (uint32_t)a.geo[2];
 
     const uint16_t* A = reinterpret_cast<const uint16_t*>(a.A);
     const uint16_t* S = reinterpret_cast<const uint16_t*>(a.S);

@@ -18,7 +18,15 @@ from flute_amd import _lib, utils  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.get()
 f16 = torch.float16
-FAM = int(os.environ.get("STAMPS_FAMILY", "3"))
+FAM = int(os.environ.get("STAMPS_FAMILY", "2"))
+dec_cases = [
+    (1, 4096, 4096, (0, -1, 8, 2, 1, -1, 0)),
+    (1, 4096, 4096, (0, -1, 16, 4, 1, -1, 0)),
+    (1, 4096, 4096, (0, -1, 8, 1, 1, -1, 0)),
+    (1, 11008, 4096, (0, -1, 16, 1, 1, -1, 0)),
+    (1, 28672, 8192, (0, -1, 16, 1, 1, -1, 0)),
+    (4, 4096, 4096, (0, -1, -1, -1, -1, -1, 0)),
+]
 cases = [
     (256, 4096, 4096, (FAM, 1, 8, 8, 1, 4, -1)),
     (256, 4096, 512, (FAM, 1, 8, 8, 1, 4, -1)),
@@ -30,7 +38,7 @@ cases = [
     (4096, 4096, 4096, (FAM, 1, 8, 1, 1, 4, -1)),
 ]
 out = []
-for (M, N, K, ovr) in cases:
+for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
     lay = bench.Layer(M, N, K, 4, 64, f16, dev, 2)
     lay.template_id = 16
     lib.flute_set_overrides(*ovr)
@@ -53,6 +61,8 @@ for (M, N, K, ovr) in cases:
          "start_us[min,med,max]": q(us[:, 0]),
          "prologue_us": q(us[:, 1] - us[:, 0]),
          "loop_cycles": q(st[:, 4]), "dma_wait_cycles": q(st[:, 7]), "pro_issue_lut": q(us[:, 5] - us[:, 0]),
+         "dec_args": q(us[:, 7] - us[:, 0]), "dec_setup": q(us[:, 4] - us[:, 7]), "dec_issue": q(us[:, 5] - us[:, 4]), "dec_lut_commit": q(us[:, 6] - us[:, 5]),
+         "dec_stage_barrier": q(us[:, 1] - us[:, 6]),
          "pro_scales": q(us[:, 6] - us[:, 5]), "pro_barrier": q(us[:, 1] - us[:, 6]),
          "mainloop_us": q(us[:, 2] - us[:, 1]),
          "epilogue_us": q(us[:, 3] - us[:, 2]),
