@@ -88,8 +88,10 @@ def test_tune_metadata_roundtrip_and_key():
     assert tune.TuneMetaData.from_dict(m.to_dict()) == m
     with pytest.raises(ValueError):
         tune.TuneMetaData.from_dict({**m.to_dict(), "dtype": "torch.int8"})
-    assert tune.get_template_key(1, 8, 16, 4, 64, 256, torch.float16) == \
-        tune.get_template_key(9, 8, 16, 4, 64, 256, torch.float16)       # M < 16 shares a template
+    assert tune.get_template_key(5, 8, 16, 4, 64, 256, torch.float16) == \
+        tune.get_template_key(9, 8, 16, 4, 64, 256, torch.float16)       # 5 <= M <= 16 shares a template
+    assert tune.get_template_key(1, 8, 16, 4, 64, 256, torch.float16) != \
+        tune.get_template_key(9, 8, 16, 4, 64, 256, torch.float16)       # decode kernel: its own entry
     cands = tune.candidate_templates(1, 4096, 4096, 4, 64, 256, torch.float16)
     assert 1 <= len(cands) < 144
     assert {flute_amd.TEMPLATE_CONFIGS[(4, t)]["TileP"] for t in cands} == {32, 64}
