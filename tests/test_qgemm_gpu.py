@@ -193,6 +193,45 @@ def test_mfma_family_for_small_M(env):
             lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
 
 
+def test_mfma_scale_block_and_ring_paths(env):
+    """The MFMA kernel's scale blocks (8 groups, fetched by LDS-DMA one block ahead) and its operand ring:
+    many blocks per wave (no K split), blocks shorter than the ring is deep (g = 32 with 4 lanes per unit),
+    a K range that starts mid-block, scale rows that are not 16-B aligned (plain staged loads), a ragged
+    last macro-step (K % 128 != 0 with 4 k-steps per weight piece) and a shallow ring (fewer waves)."""
+    lib = env.fa._lib.get()
+    cases = [
+        # bits, tile_p, g, dtype, K, N, M, overrides (family, R, waves, kw, splitk, MT, -)
+        (4, 32, 64, torch.float16, 8192, 512, 64, (2, 1, 8, 1, 1, 4, -1)),      # 16 blocks per wave
+        (4, 32, 64, torch.bfloat16, 8192, 512, 48, (2, 1, 8, 1, 1, 4, -1)),
+        (4, 32, 32, torch.float16, 2048, 512, 16, (2, 4, 8, 1, 1, 1, -1)),      # block = 2 macro-steps < ring depth
+        (4, 64, 32, torch.bfloat16, 2048, 512, 9, (2, 4, 8, 2, 1, 1, -1)),
+        (4, 32, 64, torch.float16, 4096 + 320, 512, 16, (2, 4, 8, 4, 1, 1, -1)),  # G = 69: unaligned scale rows, ragged K
+        (2, 32, 64, torch.float16, 4096 + 320, 512, 33, (2, 2, 8, 2, 1, 2, -1)),
+        (4, 32, 128, torch.float16, 3072, 512, 16, (2, 2, 4, 4, 1, 1, -1)),      # wave ranges start mid-block
+        (3, 32, 64, torch.bfloat16, 4096, 512, 20, (2, 1, 8, 2, 1, 1, -1)),
+        (3, 32, 64, torch.float16, 2048 + 64, 1024, 5, (2, 1, 4, 1, 2, 1, -1)),  # grid split-K partials (16-B stores)
+    ]
+    try:
+        for (bits, tile_p, g, dtype, K, N, M, ovr) in cases:
+            W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 97)
+            What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+            tid = template_ids_for(env.fa, bits, tile_p)[0]
+            X = (torch.randn(M, K) / 100).to(dtype)
+            lib.flute_set_overrides(*ovr)
+            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+            err = rel_err(D, X.float() @ What)
+            assert err < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, ovr, err)
+            # one-hot rows: bit-exact (each output element is one rounded product)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            D1 = run_qgemm(env, E, Q, S, table, table2, bits, g, tid)
+            ref = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks]
+            assert torch.equal(D1.float(), ref.to(dtype).float()), (bits, g, dtype, K, ovr)
+    finally:
+        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
+
+
 # ---------------------------------------------------------------------------
 # full BASELINE shapes: size-independent properties, checker runs on the GPU
 # ---------------------------------------------------------------------------
