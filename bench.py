@@ -45,7 +45,8 @@ def algorithmic_bytes(M, N, K, bits, g):
 class Layer:
     """`copies` independent packed layers of one shape, all resident in HBM."""
 
-    def __init__(self, M, N, K, bits, g, dtype, device, copies, table_values=None, seed=0):
+    def __init__(self, M, N, K, bits, g, dtype, device, copies, table_values=None, seed=0,
+                 hadamard_size=0):
         import flute_amd
         from flute_amd import utils
         self.M, self.N, self.K, self.bits, self.g, self.dtype = M, N, K, bits, g, dtype
@@ -70,6 +71,8 @@ class Layer:
             self.S.append(torch.randn(N, K // g, device=device, generator=gdev).to(dtype))
         self.template_id = None
         self.qgemm = flute_amd.qgemm
+        self.hadamard_size = hadamard_size      # > 0: flute.qgemm_hadamard (FWHT of X, then qgemm: two launches)
+        self.qgemm_hadamard = flute_amd.qgemm_hadamard
 
     def bytes(self):
         return algorithmic_bytes(self.M, self.N, self.K, self.bits, self.g)
@@ -85,6 +88,9 @@ class Layer:
 
     def step(self, i):
         c = i % len(self.Q)
+        if self.hadamard_size:
+            return self.qgemm_hadamard(self.X, self.Q[c], self.S[c], self.table, self.table2, self.ws,
+                                       self.bits, self.g, self.hadamard_size, self.template_id, self.num_sms)
         return self.qgemm(self.X, self.Q[c], self.S[c], self.table, self.table2, self.ws,
                           self.bits, self.g, self.template_id, self.num_sms)
 
@@ -240,6 +246,27 @@ def main():
                 })
                 del lay
                 torch.cuda.empty_cache()
+        # the other BASELINE.json configs, one line each (parity for them lives in tests/):
+        # [2] W3G64 bf16 Llama-3-70B shapes, [3] the TP=8 column shard of 8192x28672 (what ONE of
+        # eight GPUs runs; no collective for a column shard), [4] HIGGS pair codebook + Hadamard
+        # pre-rotation on a Gemma-2-9B shape (two launches: FWHT, qgemm)
+        bf16 = torch.bfloat16
+        for (tag, m, n, k, b, dt, had) in (
+                ("W3G64 bf16 M=1 K=8192 N=8192 (configs[2])", 1, 8192, 8192, 3, bf16, 0),
+                ("W3G64 bf16 M=1 K=8192 N=28672 (configs[2])", 1, 28672, 8192, 3, bf16, 0),
+                ("W4G64 fp16 M=1 K=8192 N=28672 full layer", 1, 28672, 8192, 4, dtype, 0),
+                ("W4G64 fp16 M=1 K=8192 N=3584 = TP-8 column shard of 8192x28672 (configs[3])", 1, 3584, 8192, 4, dtype, 0),
+                ("W4G64 fp16 M=1 K=3584 N=4096 pair codebook + hadamard_size=512 (configs[4], Gemma-2-9B)", 1, 4096, 3584, 4, dtype, 512)):
+            lay = Layer(m, n, k, b, g, dt, device, copies_for(n, k, b), None, hadamard_size=had)
+            lay.tune()
+            e_ms, _ = time_graph(lay, 300, 20, lambda: torch.cuda.synchronize())
+            us = e_ms / 300 * 1e3
+            nbytes = algorithmic_bytes(m, n, k, b, g) + (4 * m * k if had else 0)
+            extras.append({"workload": tag, "template_id": lay.template_id, "us": round(us, 3),
+                           "GBps": round(nbytes / us / 1e3, 1),
+                           "frac_hbm_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)})
+            del lay
+            torch.cuda.empty_cache()
 
     if rank == 0:
         achieved = bytes_step / (ms_per_step * 1e-3) / 1e9

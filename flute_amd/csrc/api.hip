@@ -103,6 +103,11 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
         int kw = f < waves ? f : waves;
         int splitk = f / kw;
+        // Stages (2..5) has no pipeline to size here: the tuner uses it to try the neighbouring
+        // K splits (same, half, double, quadruple)
+        if (t.stages == 3 && kw > 1) kw >>= 1;
+        if (t.stages == 4) kw <<= 1;
+        if (t.stages == 5) kw <<= 2;
         if (g_ovr.kw > 0) kw = floor_pow2(g_ovr.kw);
         if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
         if (kw > waves) kw = waves;
@@ -151,13 +156,16 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
         if (g_ovr.m_block > 0 && combo_ok(g_ovr.m_block, mt)) R = g_ovr.m_block;
         const int slabs = units * R / 16;
-        int nw = 8;
+        int nw = (t.threads >= 1024) ? 8 : 4;                     // Threads 1024 / 512 templates
         if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = floor_pow2(g_ovr.waves);
         while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
         while (kw > 1 && (long)slabs * mtiles / (nw / kw) >= 2L * num_sms * t.sms_multiple && K / kw < 1024) kw >>= 1;
+        if (t.stages == 3 && kw > 1) kw >>= 1;                    // the tuner's handle on the K split (see decode)
+        if (t.stages == 4 && kw < nw) kw <<= 1;
+        if (t.stages == 5 && kw > 2) kw >>= 2;
         if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = floor_pow2(g_ovr.kw);
         while (nw % kw) kw >>= 1;
         while (slabs % (nw / kw)) kw <<= 1;

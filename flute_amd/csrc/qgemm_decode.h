@@ -44,15 +44,17 @@ template <int BITS> struct DecCfg {
     // slots in flight per lane.  Measured on MI355X (profiles/r01_ring_depth.txt): 2 slots x 2
     // pieces (4 KiB per wave) is the optimum for b=4/2 - deeper rings get SLOWER (a wave blocks
     // at its refill load when the memory queues are full and cannot run the compute it
-    // already has data for); the 3-plane b=3 slots are 1 piece per plane and want 4.
-    static constexpr int U = (BITS == 3) ? 4 : FLUTE_DEC_U;
+    // already has data for).  b=3: 2 slots of one piece per plane keep the M=1 variant under 128
+    // VGPRs, i.e. 16 waves per CU: its 3-op field extraction makes it the most compute-heavy
+    // variant and it gains more from waves that compute while others wait than from a deeper ring.
+    static constexpr int U = FLUTE_DEC_U;
     static constexpr int LUT_BYTES = (BITS == 3) ? 64 * 128 : 65536;
 };
 
 // largest workgroup a variant may be launched with: 1024 threads cap the kernel at 128
 // VGPRs, which only the light variants fit without spilling
 __host__ __device__ constexpr int dec_max_threads(int bits, int mb) {
-    return (bits == 4 && mb <= 2) ? 1024 : 512;
+    return ((bits == 4 && mb <= 2) || (bits == 3 && mb == 1)) ? 1024 : 512;
 }
 
 struct DecodeGeom {

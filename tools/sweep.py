@@ -94,6 +94,15 @@ elif which == "tile":
         run(4096, 4096, 4096, 4, 64, f16, 16, (fam, 1, 8, 1, 1, 4, -1), steps=50)
         run(64, 8192, 8192, 3, 64, bf16, 4, (fam, -1, -1, -1, -1, -1, -1))
         run(256, 4096, 4096, 2, 64, f16, 4, (fam, -1, -1, -1, -1, -1, -1))
+elif which == "w3":
+    for (n, k) in ((8192, 8192), (28672, 8192)):
+        for waves, kw in ((16, 4), (16, 8), (16, 16), (8, 2), (8, 4), (8, 8), (4, 4), (4, 2)):
+            run(1, n, k, 3, 64, bf16, 4, (0, -1, waves, kw, 1, -1, 0))
+        run(1, n, k, 3, 64, bf16, 4, (0, -1, -1, -1, -1, -1, 0))
+    run(2, 8192, 8192, 3, 64, bf16, 4, (0, -1, -1, -1, -1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 2, 1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 4, 1, -1, 0))
 elif which == "calib":
     import time
     lib = _lib.get()
