@@ -71,7 +71,7 @@ class Layer:
             self.S.append(torch.randn(N, K // g, device=device, generator=gdev).to(dtype))
         self.template_id = None
         self.qgemm = flute_amd.qgemm
-        self.hadamard_size = hadamard_size      # > 0: flute.qgemm_hadamard (FWHT of X, then qgemm: two launches)
+        self.hadamard_size = hadamard_size      # > 0: flute.qgemm_hadamard (rotation fused into the decode kernel)
         self.qgemm_hadamard = flute_amd.qgemm_hadamard
 
     def bytes(self):
@@ -249,7 +249,7 @@ def main():
         # the other BASELINE.json configs, one line each (parity for them lives in tests/):
         # [2] W3G64 bf16 Llama-3-70B shapes, [3] the TP=8 column shard of 8192x28672 (what ONE of
         # eight GPUs runs; no collective for a column shard), [4] HIGGS pair codebook + Hadamard
-        # pre-rotation on a Gemma-2-9B shape (two launches: FWHT, qgemm)
+        # pre-rotation on a Gemma-2-9B shape (one launch: the decode kernel rotates while staging X)
         bf16 = torch.bfloat16
         for (tag, m, n, k, b, dt, had) in (
                 ("W3G64 bf16 M=1 K=8192 N=8192 (configs[2])", 1, 8192, 8192, 3, bf16, 0),
@@ -261,7 +261,7 @@ def main():
             lay.tune()
             e_ms, _ = time_graph(lay, 300, 20, lambda: torch.cuda.synchronize())
             us = e_ms / 300 * 1e3
-            nbytes = algorithmic_bytes(m, n, k, b, g) + (4 * m * k if had else 0)
+            nbytes = algorithmic_bytes(m, n, k, b, g)
             extras.append({"workload": tag, "template_id": lay.template_id, "us": round(us, 3),
                            "GBps": round(nbytes / us / 1e3, 1),
                            "frac_hbm_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)})

@@ -39,6 +39,8 @@ SYMBOLS = {
     "flute_set_overrides": (None, [c_int] * 7),
     "flute_qgemm_plan": (c_int, [c_int] * 8 + [c_size_t, ctypes.POINTER(Plan)]),
     "flute_qgemm": (c_int, [c_int] * 7 + [c_void_p] * 7 + [c_size_t, c_int, c_int, c_void_p]),
+    "flute_qgemm_hadamard": (c_int, [c_int] * 8 + [c_void_p] * 8 + [c_size_t, c_int, c_int, c_void_p]),
+    "flute_qgemm_hadamard_fused": (c_int, [c_int] * 9 + [c_size_t]),
     "flute_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
     "flute_unpack": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flute_debug_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),

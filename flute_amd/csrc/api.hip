@@ -6,6 +6,7 @@
 // (streaming decode for M <= 8, MFMA above) whose launch geometry is derived
 // from the template's knobs and the problem shape.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -269,8 +270,41 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
                 const void* A, const void* Q, void* D, const void* S, const void* QM,
                 const void* QM2, void* workspace, size_t workspace_bytes, int template_id,
                 int num_sms, void* stream) {
+    return flute_qgemm_hadamard(dtype, num_bits, group_size, 0, M, N, K, P, A, Q, D, S, QM, QM2, nullptr,
+                                workspace, workspace_bytes, template_id, num_sms, stream);
+}
+
+int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hadamard_size, int M,
+                               int N, int K, int template_id, int num_sms, size_t workspace_bytes) {
+    flute_plan p;
+    if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes, &p,
+                  nullptr))
+        return 0;
+    return (p.family == 0 && hadamard_size >= 2 && hadamard_size <= 512 &&
+            (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0) ? 1 : 0;
+}
+
+int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N,
+                         int K, int P, const void* A, const void* Q, void* D, const void* S,
+                         const void* QM, const void* QM2, void* x_scratch, void* workspace,
+                         size_t workspace_bytes, int template_id, int num_sms, void* stream) {
     (void)QM;   // single-code table: unused, the kernel reads only the pair table (as the reference)
     if (M == 0) return FLUTE_OK;
+    int had_log = 0;
+    if (hadamard_size > 1) {
+        if (hadamard_size & (hadamard_size - 1)) return FLUTE_ERR_HADAMARD_SIZE;
+        if (flute_qgemm_hadamard_fused(dtype, num_bits, group_size, hadamard_size, M, N, K, template_id,
+                                       num_sms, workspace ? workspace_bytes : 0)) {
+            had_log = ilog2(hadamard_size);              // rotated inside the decode kernel's staging
+        } else {
+            // two launches (qgemm.cpp:201-244): rotate into the caller's scratch, then the plain product
+            if (!A || !x_scratch) return FLUTE_ERR_NULL;
+            const int rc = hadamard_dispatch(dtype, A, x_scratch, (size_t)M * K, (uint32_t)hadamard_size,
+                                             reinterpret_cast<hipStream_t>(stream));
+            if (rc) return rc;
+            A = x_scratch;
+        }
+    }
     flute_plan p;
     flute_template_info t;
     if (!workspace) workspace_bytes = 0;
@@ -291,6 +325,8 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
     a.lut_shift = 0;
     a.lds_budget = kMaxLds;
     a.lkw = ilog2(p.kw);
+    a.had_log = had_log;
+    a.had_scale = 1.0f / sqrtf((float)(1 << had_log));       // as flute_hadamard: bit-identical results
     for (int i = 0; i < 10; ++i) a.geo[i] = 0;
     if (p.family == 0) {
         const DecodeGeom g = decode_geom(num_bits, p.m_block, a.lg, p.waves, p.kw, p.k_per_split, kMaxLds);

@@ -138,6 +138,8 @@ struct QGemmArgs {
     int lut_shift;          // log2(LDS replicas of the pair table): 5, 4, 3 or 0 (MFMA kernel)
     int lds_budget;         // dynamic LDS the launch was sized for (decode kernel carve)
     int lkw;                // log2(kw) (kw and the waves per workgroup are powers of two)
+    int had_log;            // decode kernel: log2 of the fused Hadamard block (0 = none, <= 9)
+    float had_scale;        // 2^(-had_log/2)
     // launch geometry computed once by the host planner (integer divisions cost the kernels'
     // prologue ~0.1 us each).  decode: kc, nbuf, gcap, log2(upw), x_off, s_off, red_off, log2(kc),
     // unit groups / workgroups (quotient, remainder); MFMA: depth, scale_bytes, slot_bytes,

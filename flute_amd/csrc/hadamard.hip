@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "fwht.h"
 
 namespace flute_amd {
 
@@ -43,45 +44,12 @@ __device__ __forceinline__ void store8(uint16_t* p, size_t base, size_t numel, c
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (uint32_t)Num<T>::from_float(v[2 * i] * scale) |
-                   ((uint32_t)Num<T>::from_float(v[2 * i + 1] * scale) << 16);
+            w[i] = (uint32_t)scale_round<T>(v[2 * i], scale) | ((uint32_t)scale_round<T>(v[2 * i + 1], scale) << 16);
         *reinterpret_cast<uint4*>(p + base) = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (base + i < numel) p[base + i] = Num<T>::from_float(v[i] * scale);
-    }
-}
-
-// butterflies over the 3 register bits (only the lowest `nbits` of them)
-__device__ __forceinline__ void reg_stages(float (&v)[8], int nbits) {
-    if (nbits >= 1) {
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) { const float a = v[i], b = v[i + 1]; v[i] = a + b; v[i + 1] = a - b; }
-    }
-    if (nbits >= 2) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (!(i & 2)) { const float a = v[i], b = v[i + 2]; v[i] = a + b; v[i + 2] = a - b; }
-    }
-    if (nbits >= 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const float a = v[i], b = v[i + 4]; v[i] = a + b; v[i + 4] = a - b; }
-    }
-}
-
-// butterflies over `nbits` lane bits (lane bit s pairs lanes l and l^(1<<s))
-__device__ __forceinline__ void lane_stages(float (&v)[8], int lane, int nbits) {
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        if (s < nbits) {
-            const bool hi = (lane >> s) & 1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float p = __shfl_xor(v[i], 1 << s, 64);
-                v[i] = hi ? (p - v[i]) : (v[i] + p);
-            }
-        }
+            if (base + i < numel) p[base + i] = scale_round<T>(v[i], scale);
     }
 }
 

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fwht.h"
 
 namespace flute_amd {
 
@@ -383,7 +384,11 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             if (pidx < sc.xpieces) {
                 const int m = (MB == 1) ? 0 : pidx / (KC / 8);
                 const int kk = (pidx - m * (KC / 8)) * 8;
-                const uint4 v = (kk < kc_len) ? make_uint4(xv[r].x, xv[r].y, xv[r].z, xv[r].w) : make_uint4(0, 0, 0, 0);
+                uint32_t w[4] = {xv[r].x, xv[r].y, xv[r].z, xv[r].w};
+                // fused pre-rotation (flute.qgemm_hadamard, qgemm.cpp:201-244): the 64 pieces of a wave
+                // are 512 consecutive k of one row = whole Hadamard blocks (K % had == 0, had <= 512)
+                if (a.had_log > 0) fwht_piece<T>(w, lane, a.had_log, a.had_scale);
+                const uint4 v = (kk < kc_len) ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
             }
         }
@@ -400,6 +405,11 @@ __global__ __launch_bounds__(dec_max_threads(BITS, MB)) void qgemv_kernel(const 
             uint4 v = make_uint4(0, 0, 0, 0);
             if (kk < kc_len)
                 v = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + kc0 + kk);
+            if (a.had_log > 0) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                fwht_piece<T>(w, lane, a.had_log, a.had_scale);
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
             *reinterpret_cast<uint4*>(xsb + (size_t)m * KC + kk) = v;
         }
         for (int pidx = nthr + tid; pidx < sc.spieces; pidx += nthr) {

@@ -74,7 +74,7 @@ def hadamard_transform(input: torch.Tensor, hadamard_size: int) -> torch.Tensor:
 
 
 def _qgemm_raw_simple(input, weight, scales, table, table2, workspace, num_bits, group_size,
-                      template_id, num_sms):
+                      template_id, num_sms, hadamard_size=0):
     _validate(input, weight, scales, table, table2, workspace, num_bits, group_size)
     K = input.shape[-1]
     N = scales.shape[0]
@@ -89,11 +89,26 @@ def _qgemm_raw_simple(input, weight, scales, table, table2, workspace, num_bits,
     M = x2d.shape[0]
     out = torch.empty((M, N), dtype=input.dtype, device=input.device)
     if M > 0:
+        lib = _lib.get()
+        scratch = None
+        if hadamard_size:
+            if hadamard_size < 1 or hadamard_size & (hadamard_size - 1) or hadamard_size > 2 ** 15:
+                _lib.check(-8)
+            if K % hadamard_size and (M * K) % hadamard_size:
+                raise RuntimeError(f"shape {tuple(input.shape)} is invalid for hadamard_size {hadamard_size}")
+            # decode-kernel launches rotate the activations while staging them; every other plan
+            # (and blocks that span rows) rotates into a scratch tensor first (qgemm.cpp:201-244)
+            if not lib.flute_qgemm_hadamard_fused(_DTYPE_ID[input.dtype], num_bits, group_size,
+                                                  hadamard_size, M, N, K, template_id, num_sms,
+                                                  workspace.numel()):
+                scratch = torch.empty_like(x2d)
         with torch.cuda.device(input.device):          # qgemm.cpp:101 OptionalCUDAGuard
-            rc = _lib.get().flute_qgemm(
-                _DTYPE_ID[input.dtype], num_bits, group_size, M, N, K, weight.shape[0],
+            rc = lib.flute_qgemm_hadamard(
+                _DTYPE_ID[input.dtype], num_bits, group_size, hadamard_size, M, N, K, weight.shape[0],
                 x2d.data_ptr(), weight.data_ptr(), out.data_ptr(), scales.data_ptr(),
-                table.data_ptr(), table2.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                table.data_ptr(), table2.data_ptr(),
+                scratch.data_ptr() if scratch is not None else None,
+                workspace.data_ptr(), workspace.numel(),
                 template_id, num_sms, _stream_ptr(input.device))   # qgemm.cpp:105 current stream
         _lib.check(rc)
     return out.reshape(input.shape[:-1] + (N,))
@@ -101,10 +116,11 @@ def _qgemm_raw_simple(input, weight, scales, table, table2, workspace, num_bits,
 
 def _qgemm_raw_simple_hadamard(input, weight, scales, table, table2, workspace, num_bits,
                                group_size, hadamard_size, template_id, num_sms):
-    # qgemm.cpp:214-244: rotate, then the plain op
-    had = hadamard_transform(input, hadamard_size)
-    return _qgemm_raw_simple(had, weight, scales, table, table2, workspace, num_bits,
-                             group_size, template_id, num_sms)
+    # qgemm.cpp:214-244: rotate, then the plain op - fused into one launch where the plan allows
+    if input.dtype not in _DTYPE_ID:
+        raise TypeError("Only fp16 and bf16 supported currently")
+    return _qgemm_raw_simple(input, weight, scales, table, table2, workspace, num_bits,
+                             group_size, template_id, num_sms, hadamard_size=hadamard_size)
 
 
 _IMPL.impl("qgemm_raw_simple", _qgemm_raw_simple)

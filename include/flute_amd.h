@@ -87,6 +87,21 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
                 const void* QM2, void* workspace, size_t workspace_bytes, int template_id,
                 int num_sms, void* stream);
 
+/* flute.qgemm_hadamard (flute/__init__.py:32-50; apply_hadamard + qgemm_raw_simple_hadamard,
+ * flute/csrc/qgemm.cpp:201-244): D = (A.reshape(-1, hadamard_size) @ H/sqrt(hadamard_size)).reshape(M,K)
+ * @ dequant(Q).  When the launch plan is the decode kernel (M <= 4) and hadamard_size <= 512 divides K,
+ * the rotation is fused into that kernel's activation staging (one launch, no round trip of the
+ * rotated activations through HBM; same fp32 butterflies and single rounding as flute_hadamard, so the
+ * result is bit-identical to the two-launch form).  Otherwise the rotated activations go to
+ * x_scratch ([M,K] T, caller-owned) with flute_hadamard and the plain product follows.
+ * flute_qgemm_hadamard_fused returns 1 when x_scratch will not be touched (may then be NULL). */
+int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N,
+                         int K, int P, const void* A, const void* Q, void* D, const void* S,
+                         const void* QM, const void* QM2, void* x_scratch, void* workspace,
+                         size_t workspace_bytes, int template_id, int num_sms, void* stream);
+int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hadamard_size, int M,
+                               int N, int K, int template_id, int num_sms, size_t workspace_bytes);
+
 /* The plan flute_qgemm would use (exposed for tests and the offline tuner). */
 int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
                      int template_id, int num_sms, size_t workspace_bytes, flute_plan* out);

@@ -346,6 +346,47 @@ def test_qgemm_hadamard(env):
         assert rel_err(out, ref) < 3e-3, (M, rel_err(out, ref))
 
 
+def test_qgemm_hadamard_fused_equals_two_launches(env):
+    """Decode-kernel plans rotate the activations while staging them (one launch); the result must be
+    BIT-identical to hadamard_transform followed by qgemm (same fp32 butterflies, one rounding), for
+    every block size the fused path takes, both dtypes, M up to the decode limit, K not a multiple
+    of 512, chunked staging (large K) and the 3-bit / 2-bit kernels."""
+    d = env.dev
+    lib = env.fa._lib.get()
+    cases = [(4, 32, 64, torch.float16, 1024, 512), (4, 64, 64, torch.bfloat16, 3584, 512),
+             (2, 32, 64, torch.float16, 1536, 512), (3, 32, 64, torch.bfloat16, 2048, 512),
+             (4, 32, 128, torch.float16, 16384, 256)]
+    for (bits, tile_p, g, dtype, K, N) in cases:
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 89)
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for h in (512, 128, 16, 2):
+            if K % h:
+                continue
+            for M in (1, 2, 3, 4):
+                if bits == 3 and M > 2:
+                    continue
+                assert lib.flute_qgemm_hadamard_fused(0 if dtype == torch.float16 else 1, bits, g, h, M, N, K,
+                                                      tid, env.num_sms, env.ws.numel()) == 1
+                X = (torch.randn(M, K) / 10).to(dtype).to(d)
+                fused = env.fa.qgemm_hadamard(X, Qd, Sd, td, t2d, env.ws, bits, g, h, tid, env.num_sms)
+                two = env.fa.qgemm(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, bits, g, tid,
+                                   env.num_sms)
+                assert torch.equal(fused, two), (bits, dtype, K, h, M)
+    # plans that cannot fuse (MFMA kernel, blocks larger than 512) take the scratch path
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 2048, 512
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=2)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    for (M, h) in ((1, 1024), (9, 512), (64, 2048)):
+        assert lib.flute_qgemm_hadamard_fused(0, bits, g, h, M, N, K, tid, env.num_sms, env.ws.numel()) == 0
+        X = (torch.randn(M, K) / 10).to(dtype).to(d)
+        out = env.fa.qgemm_hadamard(X, Q.to(d), S.to(d), table.to(d), table2.to(d), env.ws, bits, g, h,
+                                    tid, env.num_sms)
+        two = env.fa.qgemm(env.fa.hadamard_transform(X, h), Q.to(d), S.to(d), table.to(d), table2.to(d),
+                           env.ws, bits, g, tid, env.num_sms)
+        assert torch.equal(out, two), (M, h)
+
+
 # ---------------------------------------------------------------------------
 # boundary behaviour
 # ---------------------------------------------------------------------------
