@@ -106,3 +106,27 @@ def test_qgemm_null_and_empty_calls_return_before_launch():
     assert lib.flute_qgemm(*args) == -4                     # P inconsistent with N
     assert lib.flute_hadamard(0, None, None, 0, 64, None) == 0
     assert lib.flute_hadamard(0, None, None, 64, 64, None) == -9
+
+
+def test_qgemm_hadamard_entry_host_logic():
+    """flute_qgemm_hadamard: which calls fuse the rotation (decode plans, power-of-two blocks <= 512 that
+    divide K) and the argument checks that run before any launch."""
+    lib = _lib.get()
+    ws = 64 << 20
+    fused = lambda M, K, h, bits=4, tid=16: lib.flute_qgemm_hadamard_fused(0, bits, 64, h, M, 4096, K, tid, 256, ws)  # noqa: E731
+    assert fused(1, 4096, 512) == 1 and fused(4, 4096, 16) == 1 and fused(1, 3584, 512) == 1
+    assert fused(5, 4096, 512) == 0          # MFMA plan: rotated into the caller's scratch first
+    assert fused(1, 4096, 1024) == 0         # block wider than one wave's 512-element span
+    assert fused(1, 4096 + 64, 512) == 0     # blocks would straddle rows
+    assert fused(1, 4096, 48) == 0           # not a power of two
+    assert fused(3, 4096, 512, bits=3, tid=4) == 0 and fused(2, 4096, 512, bits=3, tid=4) == 1
+    head = [0, 4, 64, 512, 0, 4096, 4096, 1024]
+    tail = [None] * 8 + [0, 16, 256, None]
+    assert lib.flute_qgemm_hadamard(*(head + tail)) == 0            # M == 0
+    head[4] = 1
+    head[3] = 48
+    assert lib.flute_qgemm_hadamard(*(head + tail)) == -8           # hadamard size must be a power of two
+    head[3] = 512
+    assert lib.flute_qgemm_hadamard(*(head + tail)) == -9           # null tensors, fused plan: refused before launch
+    head[4] = 9
+    assert lib.flute_qgemm_hadamard(*(head + tail)) == -9           # unfused plan without scratch
