@@ -143,6 +143,9 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         const int mt_cap = (bits == 3) ? 2 : 4;
         if (mt > mt_cap) mt = mt_cap;
         if (t.tile_m / 16 < mt && M > 16) mt = t.tile_m / 16 >= 2 ? t.tile_m / 16 : mt;
+        // SMs_Multiple = "more, smaller workgroups": halves / quarters the row tiles per wave (and,
+        // below, raises the slab count the choice of R aims for)
+        for (int m2 = t.sms_multiple; m2 > 1 && mt > 1; m2 >>= 1) mt >>= 1;
         if (g_ovr.lut_copies == 1 || g_ovr.lut_copies == 2 || g_ovr.lut_copies == 4) mt = g_ovr.lut_copies;
         if (mt > mt_cap) mt = mt_cap;
         // instantiated (R, MT): (J/R)*MT <= 16 accumulator tiles, R in {1,2,4}, MT > 1 needs R <= 2

@@ -103,6 +103,16 @@ elif which == "w3":
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0))
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 2, 1, -1, 0))
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 4, 1, -1, 0))
+elif which == "big":
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 2, 1, -1, 0))
+    run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 8, 1, 1, -1, 0))
+    run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, 16, 2, 1, -1, 0))
+    run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, 8, 2, 1, -1, 0))
+    run(1, 28672, 8192, 3, 64, bf16, 4, (0, -1, 8, 2, 1, -1, 0))
+    run(1, 28672, 8192, 3, 64, bf16, 4, (0, -1, 4, 4, 1, -1, 0))
+    run(1, 8192, 8192, 3, 64, bf16, 4, (0, -1, 8, 8, 1, -1, 0))
+    run(4, 28672, 8192, 4, 64, f16, 16, (0, -1, -1, -1, -1, -1, 0))
 elif which == "calib":
     import time
     lib = _lib.get()
