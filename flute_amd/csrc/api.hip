@@ -341,6 +341,9 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
         const TileGeom g = tile_geom(num_bits, p.m_block, p.m_tiles, p.waves, kMaxLds);
         a.geo[0] = g.depth; a.geo[1] = g.scale_bytes; a.geo[2] = g.slot_bytes; a.geo[3] = g.wave_bytes;
         a.geo[4] = ceil_div(M, p.m_tiles * 16);
+        // slab groups a multiple of the 8 XCDs: row tiles of one slab share an XCD (qgemm_tile.h) - as long
+        // as the activations (which every XCD then reads in full) are the smaller operand
+        a.geo[5] = (((int)p.grid / p.splitk / a.geo[4]) % 8 == 0 && (long)M * 32 <= (long)num_bits * N) ? 1 : 0;
     }
 
     QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles);

@@ -143,7 +143,7 @@ struct QGemmArgs {
     // launch geometry computed once by the host planner (integer divisions cost the kernels'
     // prologue ~0.1 us each).  decode: kc, nbuf, gcap, log2(upw), x_off, s_off, red_off, log2(kc),
     // unit groups / workgroups (quotient, remainder); MFMA: depth, scale_bytes, slot_bytes,
-    // wave_bytes, row-tile count
+    // wave_bytes, row-tile count, XCD-aware block order flag
     int geo[10];
 };
 

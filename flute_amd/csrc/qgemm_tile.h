@@ -143,8 +143,19 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     int bid = blockIdx.x, split = 0, mtile = 0;
     if (a.splitk > 1) { split = bid % a.splitk; bid /= a.splitk; }
     const int mtiles = a.geo[4];
-    if (mtiles > 1) { mtile = bid % mtiles; bid /= mtiles; }
-    const int sg = bid;
+    int sg = bid;
+    if (mtiles > 1) {
+        if (a.geo[5]) {
+            // XCD-aware: consecutive blocks go to consecutive XCDs (8, one L2 each), so the row tiles
+            // that share a weight slab are given block ids 8 apart and stream it through ONE L2
+            const int j = bid >> 3;
+            mtile = j % mtiles;
+            sg = (j / mtiles) * 8 + (bid & 7);
+        } else {
+            mtile = bid % mtiles;
+            sg = bid / mtiles;
+        }
+    }
     const int m0 = mtile * (MT * 16);
     const int slab = sg * ns + sl;
     // MFMA role of this lane on the weight side: column r16 of every column tile =
