@@ -138,9 +138,10 @@ def time_eager(layer, steps, warmup):
     return start.elapsed_time(end)
 
 
-def cpu_baseline(N, K, bits, g, tile_p=32, runs=3):
+def cpu_baseline(N, K, bits, g, tile_p=32, runs=24):
     """The reference's CPU-runnable case (BASELINE.json configs[0]): closed-form unpack
-    of Q, LUT dequant, torch.matmul - i.e. the oracle, timed on the host cores."""
+    of Q, LUT dequant, torch.matmul - i.e. the oracle, timed on the host cores.  Bounded
+    sample: `runs` repetitions of the headline layer (about 10 s of CPU work)."""
     from oracle import flute_oracle as O
     import numpy as np
     torch.set_num_threads(os.cpu_count() or 1)

@@ -208,18 +208,23 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, i
     return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
 }
 
-// kernels that were already granted > 64 KB of dynamic LDS
-const void* g_big_lds[64];
+// (device, kernel) pairs already granted > 64 KB of dynamic LDS: the attribute is per device, and one
+// process may drive several GPUs (accelerate-style sharded inference)
+struct BigLds { int dev; const void* fn; };
+BigLds g_big_lds[256];
 int g_big_lds_n = 0;
 
 int ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 65536) return 0;
-    for (int i = 0; i < g_big_lds_n; ++i) if (g_big_lds[i] == fn) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return FLUTE_ERR_LAUNCH; }
+    for (int i = 0; i < g_big_lds_n; ++i)
+        if (g_big_lds[i].fn == fn && g_big_lds[i].dev == dev) return 0;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
         (void)hipGetLastError();
         return FLUTE_ERR_LAUNCH;
     }
-    if (g_big_lds_n < 64) g_big_lds[g_big_lds_n++] = fn;
+    if (g_big_lds_n < 256) g_big_lds[g_big_lds_n++] = BigLds{dev, fn};
     return 0;
 }
 
