@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--template-id", type=int, default=-1,
+                    help="skip the tuner and use this template id (profiling runs: keeps the tuner's "
+                         "candidate launches out of the kernel trace)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,7 +213,10 @@ def main():
     from oracle.flute_oracle import NF4_VALUES
     M, N, K, bits, g, dtype = 1, 4096, 4096, 4, 64, torch.float16
     layer = Layer(M, N, K, bits, g, dtype, device, copies_for(N, K, bits), NF4_VALUES, seed=rank)
-    tid = layer.tune()
+    if args.template_id >= 0:
+        tid = layer.template_id = args.template_id
+    else:
+        tid = layer.tune()
     ev_ms, wall_ms = time_graph(layer, args.steps, args.warmup, sync)
     eager_ms = time_eager(layer, min(args.steps, 500), 10)
     t = torch.tensor([ev_ms, wall_ms], device=device, dtype=torch.float64)

@@ -5,7 +5,10 @@ set -u
 out=gpurun_out/prof/bench
 mkdir -p $out
 export TMPDIR=/tmp
-CMD="python bench.py --steps 300 --warmup 20 --no-extras --no-cpu"
+# the tuner's pick first (untraced), then the traced runs launch that plan only
+TID=$(python bench.py --steps 300 --warmup 20 --no-extras --no-cpu | python -c "import json,sys; print(json.loads(sys.stdin.readline())['config']['template_id'])")
+CMD="python bench.py --steps 300 --warmup 20 --no-extras --no-cpu --template-id $TID"
+echo "profiling: $CMD"
 rocprofv3 -f csv --kernel-trace --stats -d $out/trace -o t -- $CMD > $out/trace.log 2>&1
 rocprofv3 -f csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc1 -o p -- $CMD > $out/pmc1.log 2>&1
 rocprofv3 -f csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc2 -o p -- $CMD > $out/pmc2.log 2>&1
