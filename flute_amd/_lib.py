@@ -21,7 +21,8 @@ class TemplateInfo(ctypes.Structure):
 
 class Plan(ctypes.Structure):
     _fields_ = [
-        ("family", c_int), ("m_block", c_int), ("m_tiles", c_int), ("waves", c_int), ("kw", c_int),
+        ("family", c_int), ("m_block", c_int), ("m_tiles", c_int), ("slabs_per_wave", c_int), ("waves", c_int),
+        ("kw", c_int),
         ("splitk", c_int), ("k_per_split", c_int), ("lut_copies", c_int),
         ("grid", ctypes.c_uint), ("block", ctypes.c_uint),
         ("lds_bytes", c_size_t), ("workspace_needed", c_size_t)]
@@ -62,7 +63,7 @@ def get() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.flute_abi_version() != 1:
+        if lib.flute_abi_version() != 2:
             raise ImportError("flute_amd: ABI version mismatch, rebuild libflute_amd.so")
         _lib = lib
     return _lib

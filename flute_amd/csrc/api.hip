@@ -159,10 +159,21 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         while (!combo_ok(R, mt)) R *= 2;
         while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
         if (g_ovr.m_block > 0 && combo_ok(g_ovr.m_block, mt)) R = g_ovr.m_block;
-        const int slabs = units * R / 16;
+        // SW = 2 slabs per wave (4-bit, no lane sharing, fp16 up to MT = 4 / bf16 up to MT = 2: the bf16 path
+        // keeps a second accumulator set): every activation fragment then serves 8 column tiles and the
+        // texture-path traffic per MFMA drops by 40 %.  Worth it once halving the slab count still leaves a
+        // workgroup for every CU; QuantMapMode (the last template digit) lets the tuner force either.
+        const bool sw_ok = bits == 4 && R == 1 && mt >= 2 && (dtype == 0 || mt == 2) && (units / 16) % 2 == 0;
+        int sw = 1;
+        if (sw_ok && (long)(units / 32) * mtiles >= (long)num_sms) sw = 2;
+        if (sw_ok && bits == 4 && (template_id % 4) == 3) sw = 2;
+        if (bits == 4 && (template_id % 4) == 2) sw = 1;
+        if (sw_ok && g_ovr.prescale == 2) sw = 2;
+        if (g_ovr.prescale == 1) sw = 1;
+        const int slabs = units * R / 16 / sw;                    // wave-sized column groups
         int nw = (t.threads >= 1024) ? 8 : 4;                     // Threads 1024 / 512 templates
         if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = floor_pow2(g_ovr.waves);
-        while (nw > 1 && tile_geom(bits, R, mt, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
+        while (nw > 1 && tile_geom(bits, R, mt, sw, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
@@ -185,10 +196,11 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
             splitk = ceil_div(K, kps);
         }
         if (splitk == 1) kps = K;
-        p->m_block = R; p->m_tiles = mt; p->waves = nw; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
+        p->m_block = R; p->m_tiles = mt; p->slabs_per_wave = sw; p->waves = nw; p->kw = kw; p->splitk = splitk;
+        p->k_per_split = kps;
         p->grid = (unsigned)(wgs * splitk);
         p->block = (unsigned)(nw * 64);
-        p->lds_bytes = (size_t)tile_geom(bits, R, mt, nw, kMaxLds).total;
+        p->lds_bytes = (size_t)tile_geom(bits, R, mt, sw, nw, kMaxLds).total;
         p->lut_copies = 32;
     }
     p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
@@ -196,14 +208,14 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     return FLUTE_OK;
 }
 
-QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles) {
+QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles, int sw) {
     if (family == 0) {
         const int pre = (g_ovr.prescale > 0) ? g_ovr.prescale : 0;
         if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, pre);
         if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, pre);
         return decode_kernel_b2(dtype, tile_p, mblk, pre);
     }
-    if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles);
+    if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles, sw);
     if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
     return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
 }
@@ -343,7 +355,7 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
         const int ngroups = a.units / g.upw, nwg = (int)p.grid / p.splitk;
         a.geo[8] = ngroups / nwg; a.geo[9] = ngroups % nwg;
     } else {
-        const TileGeom g = tile_geom(num_bits, p.m_block, p.m_tiles, p.waves, kMaxLds);
+        const TileGeom g = tile_geom(num_bits, p.m_block, p.m_tiles, p.slabs_per_wave, p.waves, kMaxLds);
         a.geo[0] = g.depth; a.geo[1] = g.scale_bytes; a.geo[2] = g.slot_bytes; a.geo[3] = g.wave_bytes;
         a.geo[4] = ceil_div(M, p.m_tiles * 16);
         // slab groups a multiple of the 8 XCDs: row tiles of one slab share an XCD (qgemm_tile.h) - as long
@@ -351,7 +363,7 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
         a.geo[5] = (((int)p.grid / p.splitk / a.geo[4]) % 8 == 0 && (long)M * 32 <= (long)num_bits * N) ? 1 : 0;
     }
 
-    QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles);
+    QGemmKernel fn = pick_kernel(p.family, num_bits, dtype, t.tile_p, p.m_block, p.m_tiles, p.slabs_per_wave);
     if (!fn) return FLUTE_ERR_TEMPLATE_ID;
     if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
 

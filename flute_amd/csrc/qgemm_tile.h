@@ -39,18 +39,18 @@ constexpr int TILE_GB = 8;           // scale groups per block (one 16-B DMA gra
 
 struct TileGeom {
     int scale_bytes;   // wave-private scale blocks: 2 buffers x [column tile][16 columns][8 groups]
-    int slot_bytes;    // one ring slot = one macro-step (R k-steps): NP weight + MT*R activation pieces of 1 KB
+    int slot_bytes;    // one ring slot = one macro-step (R k-steps): NP*SW weight + MT*R activation pieces of 1 KB
     int depth;         // ring slots per wave
     int wave_bytes;
     int total;         // dynamic LDS of the launch (main loop carve or epilogue partial tiles)
 };
 
-__host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int waves, int budget) {
+__host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int sw, int waves, int budget) {
     const int J = (bits == 3) ? 16 : 16 / bits;
     const int NP = (bits == 3) ? 3 : 1;
-    const int nmf = J / R;
+    const int nmf = J / R * sw;
     const int lut = (1 << (2 * bits)) * 128;
-    const int lps = NP + mt * R;
+    const int lps = NP * sw + mt * R;
     TileGeom g;
     g.scale_bytes = 2 * (nmf > 4 ? nmf : 4) * 256;
     g.slot_bytes = lps * 1024;
@@ -60,7 +60,8 @@ __host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int waves
     g.depth = d;
     g.wave_bytes = g.scale_bytes + d * g.slot_bytes;
     const int main_bytes = lut + waves * g.wave_bytes;
-    const int epi_bytes = waves * mt * nmf * 1024;
+    const int tiles = mt * nmf;
+    const int epi_bytes = waves * (tiles > 16 ? 16 : tiles) * 1024;   // partial tiles of one epilogue pass
     g.total = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     return g;
 }
@@ -96,19 +97,22 @@ template <int R> __device__ __forceinline__ int swz_q(int row) {                
     else return row << 2;
 }
 
-template <typename T, int BITS, int TILEP, int R, int MT>
+template <typename T, int BITS, int TILEP, int R, int MT, int SW = 1>
 __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     using L = Layout<BITS>;
     using NT = Num<T>;
     constexpr int J = L::J;
     constexpr int NP = L::NPLANES;
-    constexpr int NMF = J / R;                 // column tiles per k-step and row tile
+    constexpr int NMFS = J / R;                // column tiles of one slab per k-step and row tile
+    constexpr int NMF = NMFS * SW;             // SW slabs per wave: every activation fragment serves SW x NMFS tiles
     constexpr int SU = 16 / R;                 // units per slab
-    constexpr int LPS = NP + MT * R;           // DMA pieces per macro-step
+    constexpr int QP = NP * SW;                // weight pieces per macro-step
+    constexpr int LPS = QP + MT * R;           // DMA pieces per macro-step
     constexpr int GB = TILE_GB;
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;     // 32 copies: one per bank of a ds_read_b32 lane group
     constexpr bool PRE = __is_same(T, F16);
     static_assert(BITS != 3 || R == 1, "3-bit fields are not byte aligned: R = 1 only");
+    static_assert(SW == 1 || R == 1, "several slabs per wave only without lane sharing");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
         }
     }
     const int m0 = mtile * (MT * 16);
-    const int slab = sg * ns + sl;
+    const int slab = (sg * ns + sl) * SW;      // first of this wave's SW consecutive slabs
     // MFMA role of this lane on the weight side: column r16 of every column tile =
     // unit (r16 % SU) of the slab, field i*R + (r16 / SU) of that unit in tile i
     const int ul = r16 % SU;
@@ -183,10 +187,12 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     // ---- DMA roles: which 16 B of which row this lane fetches for a weight / activation piece ----
     const int lrow = lane / (4 * R);                                  // weight piece row (unit of the slab)
     const int qchunk = (lane % (4 * R)) ^ swz_q<R>(lrow);             // source chunk (8 k each) inside the macro-step
-    const uint32_t* qrow[NP];
+    const uint32_t* qrow[QP];                                         // [slab w][plane pl] -> piece w * NP + pl
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-        qrow[pl] = a.Q + (size_t)unit_row<BITS, TILEP>(slab * SU + lrow, pl, a.N) * row_words;
+    for (int w = 0; w < SW; ++w)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+            qrow[w * NP + pl] = a.Q + (size_t)unit_row<BITS, TILEP>((slab + w) * SU + lrow, pl, a.N) * row_words;
     const int arow = lane >> 2;
     const int achunk = (lane & 3) ^ swz_a(arow);
     const uint16_t* xrow[MT];
@@ -195,13 +201,13 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
         xrow[mt] = A + (size_t)min(m0 + mt * 16 + arow, a.M - 1) * a.K;
     const int klim = a.K - 8;            // a lane never reads past its row (ragged last macro-step)
 
-    // piece P of a macro-step starting at k0: P < NP weight plane P, else activations (k-step s, row tile mt)
+    // piece P of a macro-step starting at k0: P < QP weight piece (slab, plane), else activations (k-step s, row tile mt)
     auto issue_piece = [&](int P, int k0, uint32_t slot_addr) {
-        if (P < NP) {
+        if (P < QP) {
             const int kq = min(k0 + qchunk * 8, klim);
             dma16(qrow[P] + (kq >> 1), slot_addr + P * 1024);
         } else {
-            const int s = (P - NP) / MT, mt = (P - NP) % MT;
+            const int s = (P - QP) / MT, mt = (P - QP) % MT;
             const int ka = min(k0 + s * 32 + achunk * 8, klim);
             dma16(xrow[mt] + ka, slot_addr + P * 1024);
         }
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
     for (int sp = 0; sp < SPIECES; ++sp) {
         const int i = min(sp * 4 + q4, NMF - 1);                      // NMF < 4: the surplus lanes refetch the last tile
-        const int col = unit_col0<BITS, TILEP>(slab * SU + r16 % SU) + (i * R + r16 / SU) * TILEP;
+        const int col = unit_col0<BITS, TILEP>((slab + i / NMFS) * SU + r16 % SU) + ((i % NMFS) * R + r16 / SU) * TILEP;
         srow[sp] = S + (size_t)col * a.G;
     }
     const int blk_last = (nsteps > 0) ? ((ke - 1) >> lg) >> 3 : -1;     // last block this wave touches
@@ -359,9 +365,9 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                     }
                     cur_group = grp;
                 }
-                uint32_t qw[NP][4];
+                uint32_t qw[QP][4];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
+                for (int pl = 0; pl < QP; ++pl) {
                     const uint4 v = lds_ld128(slot + pl * 1024 + qread + (uint32_t)(((s * 4 + q4) ^ qswz) * 16));
                     qw[pl][0] = v.x; qw[pl][1] = v.y; qw[pl][2] = v.z; qw[pl][3] = v.w;
                 }
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if ((dbg & 2) && mt > 0) { af[mt] = af[0]; continue; }
-                    const uint4 v = lds_ld128(slot + (NP + s * MT + mt) * 1024 + aread);
+                    const uint4 v = lds_ld128(slot + (QP + s * MT + mt) * 1024 + aread);
                     af[mt] = u32x4_t{v.x, v.y, v.z, v.w};
                 }
                 // Refill of this slot for macro-step t + D, spread over the k-step: a piece may be overwritten
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                 // last k-step); one piece goes out after each column tile's MFMAs so that the wave is not
                 // parked in the texture addresser's queue for five pieces in a row
                 const bool refill = (t + D < nmacro) && !(dbg & 4);
-                const int NREF = MT + ((s == R - 1) ? NP : 0);       // constant after unrolling
+                const int NREF = MT + ((s == R - 1) ? QP : 0);       // constant after unrolling
                 if (refill) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // the pair lookups of (up to) four column tiles are issued before their first multiply:
                 // hipcc otherwise funnels them through one register (lookup, wait, multiply, 16 times)
@@ -391,17 +397,19 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
                         for (int ww = 0; ww < 4; ++ww) {
                             uint32_t addr;
+                            const int sw_ = i / NMFS, it_ = i % NMFS;         // slab and tile inside the slab (constants after unrolling)
                             if constexpr (BITS == 4 || BITS == 2) {
                                 // v_bfe_u32 + v_lshl_or_b32 (per-lane field when R lanes share the word)
-                                const uint32_t idx = (R == 1) ? ((qw[0][ww] >> (2 * BITS * i)) & ((1u << (2 * BITS)) - 1u))
-                                                              : __builtin_amdgcn_ubfe(qw[0][ww], (uint32_t)(2 * BITS) * (uint32_t)(i * R + f),
+                                const uint32_t wq = qw[sw_ * NP][ww];
+                                const uint32_t idx = (R == 1) ? ((wq >> (2 * BITS * it_)) & ((1u << (2 * BITS)) - 1u))
+                                                              : __builtin_amdgcn_ubfe(wq, (uint32_t)(2 * BITS) * (uint32_t)(it_ * R + f),
                                                                                       (uint32_t)(2 * BITS));
                                 addr = (idx << 7) | lane_off;
                             } else {
                                 uint32_t wv[NP];
 #pragma unroll
-                                for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[pl][ww];
-                                addr = (field<BITS>(wv, i) << 7) | lane_off;
+                                for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[sw_ * NP + pl][ww];
+                                addr = (field<BITS>(wv, it_) << 7) | lane_off;
                             }
                             lut[ii][ww] = (dbg & 1) ? addr : lds_ld32(addr);
                         }
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                         if (refill) {
 #pragma unroll
                             for (int q = i; q < NREF; q += NMF)
-                                issue_piece(q < MT ? NP + s * MT + q : q - MT, kb + (t + D) * (32 * R), slot);
+                                issue_piece(q < MT ? QP + s * MT + q : q - MT, kb + (t + D) * (32 * R), slot);
                         }
                     }
                 }
@@ -440,11 +448,10 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     // ---- epilogue: the kw partial tiles of a slab are summed through LDS by ALL its waves
     // (tile tt of the slab by wave tt % kw), then stored 8 B (16 B for split-K partials) per lane ----
     const int c0 = q4 * 4;                                           // first of this lane's 4 columns inside a tile
-    const int colbase = unit_col0<BITS, TILEP>(slab * SU + c0 % SU) + (c0 / SU) * TILEP;
     auto store_tile = [&](int mt, int i, const f32x4_t v) {
         const int row = m0 + mt * 16 + r16;
         if (row >= a.M) return;
-        const int col = colbase + i * R * TILEP;
+        const int col = unit_col0<BITS, TILEP>((slab + i / NMFS) * SU + c0 % SU) + ((i % NMFS) * R + c0 / SU) * TILEP;
         if (a.splitk == 1) {
             uint2 o;
             o.x = (uint32_t)NT::from_float(v[0]) | ((uint32_t)NT::from_float(v[1]) << 16);
@@ -460,19 +467,25 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < NMF; ++i) store_tile(mt, i, acc[mt][i]);
     } else {
+        // at most 16 accumulator tiles (16 KB) per wave and pass: 8 waves x 16 KB is what LDS holds
         constexpr int NT_TILES = MT * NMF;
+        constexpr int PASS = NT_TILES > 16 ? 16 : NT_TILES;
         __syncthreads();                          // every wave is done with the table and its ring
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int p0 = 0; p0 < NT_TILES; p0 += PASS) {
+            if (p0 > 0) __syncthreads();          // the previous pass has been read
 #pragma unroll
-            for (int i = 0; i < NMF; ++i)
-                *reinterpret_cast<f32x4_t*>(smem + ((size_t)(wave * NT_TILES + mt * NMF + i) * 64 + lane) * 16) = acc[mt][i];
-        __syncthreads();
-        for (int tt = kpart; tt < NT_TILES; tt += kw) {
-            f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw) * NT_TILES + tt) * 64 + lane) * 16);
-            for (int kp = 1; kp < kw; ++kp)
-                v += *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw + kp) * NT_TILES + tt) * 64 + lane) * 16);
-            store_tile(tt / NMF, tt % NMF, v);
+            for (int tl = 0; tl < PASS; ++tl) {
+                const int tt = p0 + tl;           // tile (mt, i) = (tt / NMF, tt % NMF)
+                *reinterpret_cast<f32x4_t*>(smem + ((size_t)(wave * PASS + tl) * 64 + lane) * 16) = acc[tt / NMF][tt % NMF];
+            }
+            __syncthreads();
+            for (int tl = kpart; tl < PASS; tl += kw) {
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw) * PASS + tl) * 64 + lane) * 16);
+                for (int kp = 1; kp < kw; ++kp)
+                    v += *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw + kp) * PASS + tl) * 64 + lane) * 16);
+                store_tile((p0 + tl) / NMF, (p0 + tl) % NMF, v);
+            }
         }
     }
 #ifdef FLUTE_STAMPS

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FLUTE_AMD_ABI_VERSION 1
+#define FLUTE_AMD_ABI_VERSION 2
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -63,6 +63,7 @@ typedef struct flute_plan {
                             LDS-DMA staged operands (every larger M) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
+    int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
     int waves;           /* waves per workgroup */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
     int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */
@@ -127,8 +128,8 @@ int flute_get_template_info(int num_bits, int template_id, flute_template_info* 
 /* Tuning overrides for the offline tuner / benchmarks; -1 = automatic.
  * family: 0 decode, 2 (or any value >= 1) MFMA.  prescale: 1 = decode kernel rounds lut*scale per
  * pair (fp16 only; the reference's exact arithmetic), 0/-1 = scale applied per
- * 8-k run in fp32.  For family 2, m_block overrides R and lut_copies (1/2/4) overrides the
- * row tiles per wave.  Process-global, not thread-safe. */
+ * 8-k run in fp32.  For family 2, m_block overrides R, lut_copies (1/2/4) the row tiles per wave
+ * and prescale (1/2) the slabs per wave.  Process-global, not thread-safe. */
 void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies,
                          int prescale);
 

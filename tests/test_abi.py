@@ -66,7 +66,7 @@ def test_plan_families_and_invariants():
             want = 0 if M <= dec_max else 2          # family 1 (LDS-staged MFMA) is override-only
             assert p.family == want, (bits, M, p.family)
             if p.family == 2:
-                assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4)
+                assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)
             assert p.grid >= 1 and p.block % 64 == 0 and 64 <= p.block <= 1024
             assert p.lds_bytes <= 160 * 1024
             assert p.waves * 64 == p.block and p.waves % p.kw == 0

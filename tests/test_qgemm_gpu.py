@@ -210,6 +210,9 @@ def test_mfma_scale_block_and_ring_paths(env):
         (4, 32, 128, torch.float16, 3072, 512, 16, (2, 2, 4, 4, 1, 1, -1)),      # wave ranges start mid-block
         (3, 32, 64, torch.bfloat16, 4096, 512, 20, (2, 1, 8, 2, 1, 1, -1)),
         (3, 32, 64, torch.float16, 2048 + 64, 1024, 5, (2, 1, 4, 1, 2, 1, -1)),  # grid split-K partials (16-B stores)
+        (4, 32, 64, torch.float16, 2048, 1024, 100, (2, 1, 8, 4, 1, 4, 2)),       # two slabs per wave (8 column tiles)
+        (4, 64, 64, torch.bfloat16, 2048 + 64, 1024, 40, (2, 1, 8, 2, 1, 2, 2)),
+        (4, 32, 128, torch.float16, 4096, 512, 33, (2, 1, 4, 2, 2, 2, 2)),
     ]
     try:
         for (bits, tile_p, g, dtype, K, N, M, ovr) in cases:

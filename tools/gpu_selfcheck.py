@@ -86,10 +86,13 @@ for bits, tile_p in [(4, 32), (4, 64), (2, 32), (2, 64), (3, 32)]:
          [AUTO, (-1, -1, -1, 1, 1, 32, 0), (-1, -1, -1, 2, 2, 8, 1), (-1, -1, 4, 4, 1, 1, 0), (-1, -1, 16, 8, 1, 1, 1),
           (2, 1, 2, 2, 2, -1, -1), (2, 1, 1, 1, 1, 1, -1), (2, 2, 2, 1, 4, 2, -1),
           (2, 1, -1, -1, -1, -1, -1), (2, 2, 8, 4, 2, -1, -1), (2, 4, 4, 1, 1, -1, -1), (2, 4, 8, 8, 1, -1, -1),
-          (2, 1, -1, -1, -1, 4, -1), (2, 2, 8, 2, 1, 2, -1), (2, 1, 4, 4, 2, 2, -1), (2, 2, -1, -1, -1, 4, -1)])
+          (2, 1, -1, -1, -1, 4, -1), (2, 2, 8, 2, 1, 2, -1), (2, 1, 4, 4, 2, 2, -1), (2, 2, -1, -1, -1, 4, -1),
+          (2, 1, 8, 4, 1, 2, 2), (2, 1, 8, 8, 1, 4, 2), (2, 1, 4, 1, 2, 2, 2), (2, 1, 8, 2, 1, 4, 2)])
     case(bits, tile_p, 32, torch.float16, 256, blk, [1, 7, 20], [AUTO])
     case(bits, tile_p, 256, torch.bfloat16, 2048, blk, [1, 7, 20], [AUTO])
 case(4, 32, 64, torch.float16, 4096, 4096, [1, 2, 4, 8, 16, 256], [AUTO])
+case(4, 32, 64, torch.float16, 4096, 4096, [64, 256], [(2, 1, 8, 8, 1, 2, 2), (2, 1, 8, 8, 1, 4, 2)])
+case(4, 64, 64, torch.bfloat16, 2048, 1024, [33, 100], [(2, 1, 8, 4, 1, 2, 2), (2, 1, 8, 8, 1, 2, 2)])
 case(4, 64, 64, torch.float16, 4096, 11008, [1, 16, 256], [AUTO])
 case(3, 32, 64, torch.bfloat16, 8192, 8192, [1, 4, 16, 64], [AUTO])
 case(2, 32, 64, torch.float16, 14336, 4096, [1, 3, 32], [AUTO])

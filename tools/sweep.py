@@ -113,6 +113,21 @@ elif which == "big":
     run(1, 28672, 8192, 3, 64, bf16, 4, (0, -1, 4, 4, 1, -1, 0))
     run(1, 8192, 8192, 3, 64, bf16, 4, (0, -1, 8, 8, 1, -1, 0))
     run(4, 28672, 8192, 4, 64, f16, 16, (0, -1, -1, -1, -1, -1, 0))
+elif which == "sw":
+    # two slabs per wave against one (prescale slot of the overrides: 1 / 2)
+    for swv in (1, 2):
+        run(256, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, swv))
+        run(256, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 2, swv))
+        run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, swv))
+        run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, swv))
+        run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, swv))
+        run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 2, swv))
+        run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, swv))
+        run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, swv))
+        run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 8, 1, 4, swv))
+        run(4096, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 1, 1, 4, swv), steps=50)
+        run(4096, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, swv), steps=50)
+        run(256, 4096, 4096, 4, 64, bf16, 16, (2, 1, 8, 8, 1, 2, swv))
 elif which == "calib":
     import time
     lib = _lib.get()
