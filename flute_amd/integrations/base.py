@@ -2,9 +2,11 @@
 
 Same constructor, buffers (`weight[P,K] int16`, `scales[N,G]`, `tables[2^b]`,
 `tables2`), extra-state and forward semantics (in-place bias add) as the
-reference.  The model-walking quantizer / CLI of base.py:44-200,329-388 is
-outside the hot path.
+reference.  `prepare_model_flute` is the model-walking NormalFloat quantizer of
+base.py:44-200 for plain `nn.Linear` layers (the bitsandbytes / learnable-scale
+sources and the CLI of base.py:329-388 are outside the hot path).
 """
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -99,3 +101,64 @@ class FluteLinear(torch.nn.Module):
             with torch.no_grad():
                 layer.bias.copy_(bias)
         return layer
+
+
+@torch.no_grad()
+def prepare_model_flute(name: str, module: torch.nn.Module, num_bits: int, group_size: int,
+                        example_batch_size: int, fake: bool = False, handle_hooks: bool = False,
+                        custom_scales_dict: Optional[Dict[str, torch.Tensor]] = None) -> None:
+    """Replace every fp16/bf16 `nn.Linear` under `module` by a `FluteLinear` holding its
+    NormalFloat-quantized weights, tuned and packed for this GPU (flute/integrations/base.py:44-200).
+
+    `fake=True` keeps the layers and overwrites their weights with the kernel-faithful fake
+    quantization (base.py:84-100), which is what the quantized model must reproduce.
+    accelerate hooks on a replaced layer are moved to the new layer when `handle_hooks` is set."""
+    import flute_amd.nf_utils
+    import flute_amd.tune
+
+    def _replace(_name: str, _module: torch.nn.Module) -> None:
+        for child_name, child in _module.named_children():
+            full = f"{_name}.{child_name}"
+            if not isinstance(child, torch.nn.Linear):
+                _replace(full, child)
+                continue
+            if child.weight.dtype not in (torch.float16, torch.bfloat16):
+                raise NotImplementedError(f"{full}: only fp16 / bf16 layers are quantized")
+            if child.in_features % group_size or child.in_features % 64 or \
+                    child.out_features % (512 if num_bits == 3 else 128):
+                raise ValueError(f"{full}: shape {tuple(child.weight.shape)} is not packable with group size {group_size}")
+            dev = child.weight.device
+            if dev.type != "cuda":
+                raise ValueError(f"{full}: quantization and tuning run on the layer's GPU")
+            if fake:
+                new_weight = flute_amd.nf_utils.nf_quantize_2(child.weight, num_bits, group_size, child.weight.dtype)
+                child.weight = torch.nn.Parameter(new_weight, requires_grad=False)     # assignment: no casts
+                continue
+            hook = None
+            if handle_hooks:
+                if child._backward_hooks or child._forward_hooks or child._forward_pre_hooks:
+                    raise NotImplementedError(f"{full}: PyTorch hooks are not carried over")
+                hook = getattr(child, "_hf_hook", None)
+            elif getattr(child, "_hf_hook", None) is not None:
+                raise ValueError(f"`{full}` has an accelerate hook (pass handle_hooks=True)")
+            custom = custom_scales_dict[full] if custom_scales_dict is not None else None
+            _, codes, scales, qmap = flute_amd.nf_utils.nf_quantize(child.weight, num_bits, group_size, custom)
+            example = torch.randn(example_batch_size, child.in_features, dtype=child.weight.dtype, device=dev)
+            Q, meta = flute_amd.tune.tune_and_pack(example, codes.to(torch.uint8).T.contiguous(), num_bits, group_size)
+            new = FluteLinear(child.in_features, child.out_features, num_bits, group_size, meta.template_id,
+                              workspace_lazy_init=False, bias=child.bias is not None, device=dev,
+                              dtype=child.weight.dtype)
+            new.weight.copy_(Q)
+            new.scales.copy_(scales.view(new.scales.shape).to(new.scales.dtype))
+            new.tables.copy_(qmap.to(new.tables.dtype))
+            new.tables2.copy_(flute_amd.utils.make_qmap2_from_qmap(new.tables))
+            if new.bias is not None:
+                new.bias.copy_(child.bias)
+            setattr(_module, child_name, new)
+            if hook is not None:
+                from accelerate.hooks import add_hook_to_module
+                add_hook_to_module(new, hook)
+
+    if not fake:
+        warnings.warn("prepare_model_flute tunes every distinct layer shape on the GPU (a few seconds each)")
+    _replace(name, module)

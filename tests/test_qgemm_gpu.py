@@ -433,6 +433,42 @@ def test_batch_dims_errors_and_graph(env):
     assert rel_err(static_out.cpu(), xg.cpu().float() @ What) < FP16_TOL
 
 
+def test_prepare_model_flute_matches_fake_quantized_model(env):
+    """flute/integrations/base.py:44-200: every nn.Linear becomes a FluteLinear (NF codes, tuned + packed);
+    the quantized model must reproduce the fake-quantized fp16 model (kernel-faithful rounding, base.py:84-100)."""
+    import copy
+    from flute_amd.integrations.base import FluteLinear, prepare_model_flute
+    d = env.dev
+    torch.manual_seed(4)
+
+    class Block(torch.nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.up = torch.nn.Linear(dim, 2 * dim, bias=True)
+            self.act = torch.nn.GELU()
+            self.down = torch.nn.Linear(2 * dim, dim, bias=False)
+            self.norm = torch.nn.LayerNorm(dim)
+
+        def forward(self, x):
+            return self.norm(self.down(self.act(self.up(x))))
+
+    for dtype, bits, dim, tol in ((torch.float16, 4, 256, 2e-3), (torch.bfloat16, 3, 512, 1.5e-2)):
+        model = torch.nn.Sequential(Block(dim), Block(dim)).to(device=d, dtype=dtype)
+        fake = copy.deepcopy(model)
+        prepare_model_flute("model", fake, bits, 64, example_batch_size=1, fake=True)
+        prepare_model_flute("model", model, bits, 64, example_batch_size=1)
+        assert all(isinstance(b.up, FluteLinear) and isinstance(b.down, FluteLinear) for b in model)
+        assert model[0].up.weight.dtype == torch.int16 and model[0].up.bias is not None
+        for M in (1, 7, 33):
+            x = torch.randn(M, dim, device=d, dtype=dtype)
+            with torch.no_grad():                         # inference only: the op has no autograd formula (as the reference)
+                y, y_ref = model(x), fake(x)
+            assert rel_err(y.cpu(), y_ref.cpu()) < tol, (dtype, M, rel_err(y.cpu(), y_ref.cpu()))
+    cpu_model = torch.nn.Sequential(torch.nn.Linear(64, 64)).half()
+    with pytest.raises(ValueError):
+        prepare_model_flute("m", cpu_model, 4, 64, 1)            # no CPU path
+
+
 def test_flute_linear_and_repack(env):
     from flute_amd.integrations.base import FluteLinear
     from flute_amd import tune
