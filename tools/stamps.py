@@ -67,6 +67,9 @@ for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
          "mainloop_us": q(us[:, 2] - us[:, 1]),
          "epilogue_us": q(us[:, 3] - us[:, 2]),
          "end_us": q(us[:, 3])}
+    # keep only the fields of the kernel that ran
+    drop = ('dec_',) if FAM != 0 else ('pro_', 'loop_cycles', 'dma_wait_cycles')
+    r = {k: v for k, v in r.items() if not k.startswith(drop)}
     out.append(r)
     print(json.dumps(r), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
