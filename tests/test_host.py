@@ -151,3 +151,18 @@ def test_install_as_flute_alias():
     import flute.tune
     import flute.utils
     assert flute.qgemm is flute_amd.qgemm and flute.tune.TuneMetaData is tune.TuneMetaData
+
+
+def test_prepare_model_flute_host_checks():
+    """flute/integrations/base.py:44-200: the model walker refuses what it cannot quantize before touching a GPU."""
+    from flute_amd.integrations.base import prepare_model_flute
+    with pytest.raises(ValueError):                              # quantization and tuning run on the layer's GPU
+        prepare_model_flute("m", torch.nn.Sequential(torch.nn.Linear(128, 128)).half(), 4, 64, 1)
+    with pytest.raises(NotImplementedError):                     # fp32 layers are not quantized (base.py:80-81)
+        prepare_model_flute("m", torch.nn.Sequential(torch.nn.Linear(128, 128)), 4, 64, 1)
+    with pytest.raises(ValueError):                              # in_features must hold whole groups and 64-k lines
+        prepare_model_flute("m", torch.nn.Sequential(torch.nn.Linear(96, 128)).half(), 4, 64, 1)
+    # nothing to replace: a no-op
+    m = torch.nn.Sequential(torch.nn.LayerNorm(8))
+    prepare_model_flute("m", m, 4, 64, 1, fake=True)
+    assert isinstance(m[0], torch.nn.LayerNorm)
