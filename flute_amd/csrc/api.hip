@@ -7,6 +7,7 @@
 // from the template's knobs and the problem shape.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <mutex>
 #include <stdint.h>
 #include <string.h>
 
@@ -225,9 +226,11 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, i
 struct BigLds { int dev; const void* fn; };
 BigLds g_big_lds[256];
 int g_big_lds_n = 0;
+std::mutex g_big_lds_mu;                       // flute_qgemm may be called from several host threads
 
 int ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 65536) return 0;
+    std::lock_guard<std::mutex> lock(g_big_lds_mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return FLUTE_ERR_LAUNCH; }
     for (int i = 0; i < g_big_lds_n; ++i)
