@@ -235,12 +235,12 @@ def main():
     extras = []
     if rank == 0 and not args.no_extras:
         for (n, k) in ((4096, 4096), (11008, 4096)):
-            for m in (1, 16, 256):
+            for m in (1, 16, 256) + ((4096,) if n == 4096 else ()):      # 4096: prefill, MFMA utilisation
                 if (n, k, m) == (4096, 4096, 1):
                     continue
                 lay = Layer(m, n, k, bits, g, dtype, device, copies_for(n, k, bits), NF4_VALUES)
                 lay.tune()
-                steps = 500 if m < 256 else 200
+                steps = 500 if m < 256 else (200 if m < 1024 else 60)
                 e_ms, _ = time_graph(lay, steps, 20, lambda: torch.cuda.synchronize())
                 us = e_ms / steps * 1e3
                 extras.append({
