@@ -63,7 +63,7 @@ def test_plan_families_and_invariants():
         for M in (1, 2, 3, 4, 5, 8, 16, 17, 64, 256, 1000):
             rc, p = plan(M, 4096, 4096, bits=bits, tid=tid)
             assert rc == 0
-            want = 0 if M <= dec_max else 2          # family 1 (LDS-staged MFMA) is override-only
+            want = 0 if M <= dec_max else 2          # decode kernel up to its row limit, MFMA kernel beyond
             assert p.family == want, (bits, M, p.family)
             if p.family == 2:
                 assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)

@@ -194,9 +194,8 @@ elif which == "mt":
                 continue
             run(M, 11008, 4096, 4, 64, f16, 16, (2, R, 8, kw, 1, MT, -1), steps=100)
     run(256, 4096, 4096, 4, 64, bf16, 16, (2, 1, 8, 8, 1, 4, -1), steps=200)
-    run(256, 4096, 4096, 4, 64, f16, 16, (1, 1, -1, -1, 2, 32, -1), steps=200)
     run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, -1), steps=100)
-elif which == "m16":
+elif which == "smallM":
     for M in (1, 4, 8, 16):
         for R in (1, 2, 4):
             for nw, kw in ((8, 8), (8, 4), (4, 4)):
@@ -210,15 +209,6 @@ elif which == "m16":
     run(16, 8192, 8192, 3, 64, bf16, 4, (2, 1, -1, -1, -1, -1, -1))
     run(16, 4096, 4096, 2, 64, f16, 4, (2, 4, -1, -1, -1, -1, -1))
 else:
-    for M in (5, 8, 16, 32, 64, 256):
-        for mt in (1, 2, 4):
-            if mt * 16 > max(M, 16):
-                continue
-            for splitk in (1, 2, 4):
-                run(M, 4096, 4096, 4, 64, f16, 16, (1, mt, -1, -1, splitk, 32, -1))
-    for M in (16, 256):
-        for mt in (1, 4):
-            run(M, 11008, 4096, 4, 64, f16, 16, (1, mt, -1, -1, -1, 32, -1))
-    run(16, 8192, 8192, 3, 64, bf16, 4, (1, 1, -1, -1, -1, 32, -1))
+    raise SystemExit(f"unknown sweep mode {which!r}")
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(rows, open(f"gpurun_out/sweep_{which}.json", "w"), indent=1)
