@@ -36,6 +36,10 @@
 namespace flute_amd {
 
 constexpr int TILE_GB = 8;           // scale groups per block (one 16-B DMA granule per column)
+#ifndef FLUTE_TILE_LUT_SHIFT
+#define FLUTE_TILE_LUT_SHIFT 7        // log2 bytes per pair-table entry: 7 = 32 copies (conflict-free), 6 = 16 copies
+#endif
+constexpr int TILE_LUT_SHIFT = FLUTE_TILE_LUT_SHIFT;
 
 struct TileGeom {
     int scale_bytes;   // wave-private scale blocks: 2 buffers x [column tile][16 columns][8 groups]
@@ -49,7 +53,7 @@ __host__ __device__ inline TileGeom tile_geom(int bits, int R, int mt, int sw, i
     const int J = (bits == 3) ? 16 : 16 / bits;
     const int NP = (bits == 3) ? 3 : 1;
     const int nmf = J / R * sw;
-    const int lut = (1 << (2 * bits)) * 128;
+    const int lut = (1 << (2 * bits)) << TILE_LUT_SHIFT;
     const int lps = NP * sw + mt * R;
     TileGeom g;
     g.scale_bytes = 2 * (nmf > 4 ? nmf : 4) * 256;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     constexpr int QP = NP * SW;                // weight pieces per macro-step
     constexpr int LPS = QP + MT * R;           // DMA pieces per macro-step
     constexpr int GB = TILE_GB;
-    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;     // 32 copies: one per bank of a ds_read_b32 lane group
+    constexpr int LUT_BYTES = (1 << (2 * BITS)) << TILE_LUT_SHIFT;   // 32 copies: one per bank of a ds_read_b32 lane group
     constexpr bool PRE = __is_same(T, F16);
     static_assert(BITS != 3 || R == 1, "3-bit fields are not byte aligned: R = 1 only");
     static_assert(SW == 1 || R == 1, "several slabs per wave only without lane sharing");
@@ -251,12 +255,13 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     // ---- prologue: everything the first k-step needs travels together (one memory latency):
     // pair-table words (registers), first scale block and ring slot 0 (DMA) ----
     constexpr int ENT = 1 << (2 * BITS);
-    constexpr int LUT_R = (ENT * 2 + 511) / 512;                      // table halves per thread at 512 threads
+    constexpr int LPC = (1 << TILE_LUT_SHIFT) / 64;                   // 64-B pieces per table entry
+    constexpr int LUT_R = (ENT * LPC + 511) / 512;                    // table pieces per thread at 512 threads
     uint32_t lutv[LUT_R];
 #pragma unroll
     for (int r = 0; r < LUT_R; ++r) {
         const int p = tid + r * nthr;
-        lutv[r] = (p < ENT * 2) ? a.QM2[p >> 1] : 0u;
+        lutv[r] = (p < ENT * LPC) ? a.QM2[p / LPC] : 0u;
     }
     if (nsteps > 0 && sdma) issue_scales((kb >> lg) >> 3);
     if (nmacro > 0) issue(0, ring0);
@@ -266,21 +271,21 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     const uint32_t qread = (uint32_t)(ul * (4 * R)) * 16;            // + ((s*4 + q4) ^ swz) * 16
     const int qswz = swz_q<R>(ul);
     const uint32_t aread = (uint32_t)(r16 * 4 + (q4 ^ swz_a(r16))) * 16;
-    const uint32_t lane_off = (uint32_t)(lane & 31) * 4;              // table copy of this lane
+    const uint32_t lane_off = (uint32_t)(lane & ((1 << (TILE_LUT_SHIFT - 2)) - 1)) * 4;   // table copy of this lane
 
     // ---- pair table: entry e at [e * 128, +128): 32 copies of its 4 bytes ----
 #pragma unroll
     for (int r = 0; r < LUT_R; ++r) {
         const int p = tid + r * nthr;
-        if (p < ENT * 2) {
-            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 1) * 128 + (p & 1) * 64);
+        if (p < ENT * LPC) {
+            uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p / LPC) * (LPC * 64) + (p % LPC) * 64);
             const uint4 vv = make_uint4(lutv[r], lutv[r], lutv[r], lutv[r]);
             d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
         }
     }
-    for (int p = tid + LUT_R * nthr; p < ENT * 2; p += nthr) {        // small workgroups only
-        const uint32_t v = a.QM2[p >> 1];
-        uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p >> 1) * 128 + (p & 1) * 64);
+    for (int p = tid + LUT_R * nthr; p < ENT * LPC; p += nthr) {      // small workgroups only
+        const uint32_t v = a.QM2[p / LPC];
+        uint4* d = reinterpret_cast<uint4*>(smem + (size_t)(p / LPC) * (LPC * 64) + (p % LPC) * 64);
         const uint4 vv = make_uint4(v, v, v, v);
         d[0] = vv; d[1] = vv; d[2] = vv; d[3] = vv;
     }
@@ -404,12 +409,12 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                                 const uint32_t idx = (R == 1) ? ((wq >> (2 * BITS * it_)) & ((1u << (2 * BITS)) - 1u))
                                                               : __builtin_amdgcn_ubfe(wq, (uint32_t)(2 * BITS) * (uint32_t)(it_ * R + f),
                                                                                       (uint32_t)(2 * BITS));
-                                addr = (idx << 7) | lane_off;
+                                addr = (idx << TILE_LUT_SHIFT) | lane_off;
                             } else {
                                 uint32_t wv[NP];
 #pragma unroll
                                 for (int pl = 0; pl < NP; ++pl) wv[pl] = qw[sw_ * NP + pl][ww];
-                                addr = (field<BITS>(wv, it_) << 7) | lane_off;
+                                addr = (field<BITS>(wv, it_) << TILE_LUT_SHIFT) | lane_off;
                             }
                             lut[ii][ww] = (dbg & 1) ? addr : lds_ld32(addr);
                         }
