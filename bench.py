@@ -83,7 +83,7 @@ class Layer:
     def tune(self):
         from flute_amd import tune
         self.template_id = tune._tune(self.M, self.N, self.K, self.bits, self.g, self.num_sms,
-                                      self.dtype, self.X.device, num_seeds=1, rep=40)
+                                      self.dtype, self.X.device, num_seeds=1, rep=120)
         return self.template_id
 
     def step(self, i):
