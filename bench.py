@@ -275,6 +275,31 @@ def main():
             del lay
             torch.cuda.empty_cache()
 
+        # the one speed figure the reference publishes for this path (intro-figure.jpg, README.md:135-137):
+        # qgemm against torch.mm in fp16, W4G128, N = K = 8192, batch 1..32 (A100 ~2.05x, A6000 ~3.1x)
+        n = k = 8192
+        wcopies = [torch.randn(k, n, device=device, dtype=dtype) for _ in range(3)]      # 3 x 134 MB > L3
+
+        class _Dense:
+            def __init__(self, m):
+                self.X = torch.randn(m, k, device=device, dtype=dtype)
+
+            def step(self, i):
+                return torch.mm(self.X, wcopies[i % 3])
+
+        for m in (1, 16, 32):
+            lay = Layer(m, n, k, 4, 128, dtype, device, copies_for(n, k, 4), None)
+            lay.tune()
+            q_ms, _ = time_graph(lay, 200, 10, lambda: torch.cuda.synchronize())
+            d_ms, _ = time_graph(_Dense(m), 200, 10, lambda: torch.cuda.synchronize())
+            extras.append({"workload": f"W4G128 fp16 M={m} K=8192 N=8192 vs torch.mm fp16 (reference's intro figure)",
+                           "template_id": lay.template_id, "us": round(q_ms / 200 * 1e3, 3),
+                           "torch_mm_us": round(d_ms / 200 * 1e3, 3), "speedup_vs_torch_mm": round(d_ms / q_ms, 2)})
+            del lay
+            torch.cuda.empty_cache()
+        del wcopies
+        torch.cuda.empty_cache()
+
     if rank == 0:
         achieved = bytes_step / (ms_per_step * 1e-3) / 1e9
         traffic = None      # HBM bytes per launch from the committed PMC passes of this same command
