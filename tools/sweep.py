@@ -128,6 +128,12 @@ elif which == "sw":
         run(4096, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 1, 1, 4, swv), steps=50)
         run(4096, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, swv), steps=50)
         run(256, 4096, 4096, 4, 64, bf16, 16, (2, 1, 8, 8, 1, 2, swv))
+elif which == "n11008":
+    for waves, kw in ((16, 1), (16, 2), (16, 4), (16, 8), (8, 1), (8, 2), (8, 4), (8, 8), (4, 1), (4, 2), (4, 4)):
+        run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
+    for waves, kw in ((16, 2), (16, 4), (8, 2), (8, 4)):
+        run(1, 14336, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
+        run(1, 4096, 14336, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
 elif which == "calib":
     import time
     lib = _lib.get()
