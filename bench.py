@@ -16,7 +16,10 @@ Rank 0 prints ONE JSON line (contract in the task description) carrying
 stream) and `cpu_baseline` (the CPU oracle = the reference's test formula,
 dequant + torch.mm, timed on this host's cores).  N > 1: one process per GPU,
 independent replicas of the same layer (the path has no collective; weak
-scaling), barrier + max-over-ranks timing.
+scaling), barrier + max-over-ranks timing; the line then also carries
+`tp_mlp_pair`: BASELINE.json configs[3], the 8192x28672 projection pair sharded
+N-way (column-parallel -> row-parallel + ONE RCCL all-reduce), kernels alone and
+with the collective.  The single-GPU extras and the CPU baseline run at N=1 only.
 """
 import argparse
 import json
@@ -179,6 +182,50 @@ def cpu_baseline(N, K, bits, g, tile_p=32, runs=24):
     }
 
 
+def tp_mlp_pair(world, rank, device, dist, iters=200):
+    """BASELINE.json configs[3] on `world` GPUs: the 8192x28672 up projection N-sharded (column-parallel, no
+    collective) feeding the 28672x8192 down projection K-sharded (row-parallel, ONE all-reduce of M*8192*2 B
+    over RCCL/xGMI) - flute_amd/tp.py.  Each rank builds its own shard directly (random packed data).  Reported:
+    the two kernels alone and the pair including the all-reduce, max over ranks, eager launches."""
+    try:
+        bits, g, dtype, M, H, F = 4, 64, torch.float16, 1, 8192, 28672
+        if F % (world * 256):
+            return {"skipped": f"28672 does not split {world}-way on packed column blocks"}
+        up = Layer(M, F // world, H, bits, g, dtype, device, 4, None, seed=rank)
+        down = Layer(M, H, F // world, bits, g, dtype, device, 4, None, seed=rank)
+        up.tune()
+        down.tune()
+
+        def run(collective):
+            for i in range(10):
+                up.step(i); y = down.step(i)
+                if collective:
+                    dist.all_reduce(y)
+            torch.cuda.synchronize()
+            dist.barrier(device_ids=[device.index])
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for i in range(iters):
+                up.step(i); y = down.step(i)
+                if collective:
+                    dist.all_reduce(y)
+            e.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([s.elapsed_time(e) / iters * 1e3], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(t.item(), 3)
+
+        k_us, kc_us = run(False), run(True)
+        nbytes = world * (up.bytes() + down.bytes())
+        return {"workload": f"W4G64 fp16 M=1: 8192x28672 column-parallel -> 28672x8192 row-parallel, TP={world}",
+                "kernels_us": k_us, "kernels_plus_allreduce_us": kc_us,
+                "allreduce_bytes": 2 * M * H, "launch": "eager (host launch overhead included in both)",
+                "whole_job_GBps_kernels": round(nbytes / k_us / 1e3, 1),
+                "whole_job_GBps_with_allreduce": round(nbytes / kc_us / 1e3, 1)}
+    except Exception as exc:          # never lose the headline line to the optional leg
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +244,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # FLUTE_BENCH_FORCE_DIST=1: take the process-group path on one GPU too (exercises the TP leg under torchrun)
+    if world > 1 or os.environ.get("FLUTE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
@@ -232,8 +280,10 @@ def main():
     hot.template_id = tid
     hot_ms, _ = time_graph(hot, args.steps, args.warmup, lambda: torch.cuda.synchronize())
 
+    tp_pair = tp_mlp_pair(world, rank, device, dist) if dist is not None else None
+
     extras = []
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and dist is None and not args.no_extras:
         for (n, k) in ((4096, 4096), (11008, 4096)):
             for m in (1, 16, 256) + ((4096,) if n == 4096 else ()):      # 4096: prefill, MFMA utilisation
                 if (n, k, m) == (4096, 4096, 1):
@@ -334,7 +384,9 @@ def main():
             "wall_ms_timed_region": round(wall_ms, 3),
             "extras": extras,
         }
-        if not args.no_cpu:
+        if tp_pair is not None:
+            out["tp_mlp_pair"] = tp_pair
+        if dist is None and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, K, bits, g)
         print(json.dumps(out))
     if dist is not None:

@@ -175,6 +175,11 @@ elif which == "quick":
     run(256, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 2, -1), steps=200)
     run(256, 11008, 4096, 4, 64, f16, 16, (2, 1, 8, 2, 1, 4, -1), steps=100)
     run(1024, 4096, 4096, 4, 64, f16, 16, (2, 1, 8, 4, 1, 4, -1), steps=100)
+elif which == "w4":         # fewer, fatter waves: less launch skew, less latency hiding
+    for waves, kw in ((8, 2), (4, 1), (4, 2), (4, 4), (2, 1), (2, 2), (8, 2)):
+        run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
+    for waves, kw in ((16, 1), (4, 1), (4, 2), (4, 4), (8, 1)):
+        run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
 elif which == "ring":
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0), steps=100)
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 8, 1, 1, -1, 0), steps=100)
