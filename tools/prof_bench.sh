@@ -2,6 +2,7 @@
 # rocprofv3 passes over the bench command (run on the GPU box): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in their own PMC passes (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE x2 correction on gfx950).
 set -u
+cd "$(dirname "$0")/.."          # the bench command and gpurun_out/ are relative to the repo root
 out=gpurun_out/prof/bench
 mkdir -p $out
 export TMPDIR=/tmp
