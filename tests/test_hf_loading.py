@@ -1,0 +1,159 @@
+"""Load-time path of a FLUTE checkpoint (flute_amd/integrations/huggingface.py; reference
+flute/integrations/huggingface.py:84-236): module replacement and the transformers registration on CPU,
+the repack of a foreign-GPU checkpoint on the GPU."""
+import pytest
+import torch
+
+from flute_amd.integrations import huggingface as hf
+from flute_amd.integrations.base import FluteLinear
+
+
+class _Block(torch.nn.Module):
+    def __init__(self, d, f, dtype):
+        super().__init__()
+        self.up_proj = torch.nn.Linear(d, f, bias=False, dtype=dtype)
+        self.down_proj = torch.nn.Linear(f, d, bias=True, dtype=dtype)
+
+    def forward(self, x):
+        return self.down_proj(torch.nn.functional.silu(self.up_proj(x)))
+
+
+class _Tiny(torch.nn.Module):
+    def __init__(self, d=512, f=1024, dtype=torch.float16):
+        super().__init__()
+        self.layers = torch.nn.ModuleList([_Block(d, f, dtype), _Block(d, f, dtype)])
+        self.lm_head = torch.nn.Linear(d, 64, bias=False, dtype=dtype)
+
+    def forward(self, x):
+        for blk in self.layers:
+            x = x + blk(x)
+        return x
+
+
+def test_replace_with_flute_linear_swaps_everything_but_the_skipped_modules():
+    model = _Tiny()
+    model, replaced = hf.replace_with_flute_linear(model, num_bits=4, group_size=64)
+    assert replaced
+    assert isinstance(model.lm_head, torch.nn.Linear) and not isinstance(model.lm_head, FluteLinear)
+    for blk in model.layers:
+        for name, (k, n, has_bias) in {"up_proj": (512, 1024, False), "down_proj": (1024, 512, True)}.items():
+            lin = getattr(blk, name)
+            assert isinstance(lin, FluteLinear) and lin.needs_repacking and lin.template_id is None
+            assert lin.source_cls is torch.nn.Linear
+            assert lin.weight.shape == (4 * n // 16, k) and lin.weight.dtype == torch.int16
+            assert lin.weight.device.type == "meta" and lin.scales.shape == (n, k // 64)
+            assert (lin.bias is not None) == has_bias
+            assert not any(p.requires_grad for p in lin.parameters())
+    # dotted paths and prefixes are honoured (reference :103-108)
+    model2, _ = hf.replace_with_flute_linear(_Tiny(), 4, 64, modules_to_not_convert=["layers.0", "lm_head"])
+    assert not isinstance(model2.layers[0].up_proj, FluteLinear)
+    assert isinstance(model2.layers[1].up_proj, FluteLinear)
+    # the checkpoint's extra state supplies the id the weights were packed with
+    lin = model.layers[0].up_proj
+    lin.set_extra_state({"num_bits": 4, "group_size": 64, "template_id": 7})
+    assert lin.template_id == 7
+    with pytest.raises(ValueError):
+        lin.set_extra_state({"num_bits": 4, "group_size": 64, "template_id": 8})
+
+
+def test_template_id_callback_and_nothing_to_replace():
+    seen = []
+
+    def tid(N, K, dtype):
+        seen.append((N, K, dtype))
+        return 3
+    model, _ = hf.replace_with_flute_linear(_Tiny(), 4, 64, template_id_of=tid)
+    assert model.layers[1].down_proj.template_id == 3
+    assert (1024, 512, torch.float16) in seen and (512, 1024, torch.float16) in seen
+    _, replaced = hf.replace_with_flute_linear(torch.nn.Sequential(torch.nn.ReLU()), 4, 64)
+    assert not replaced
+
+
+def test_transformers_registration_and_quantizer_hooks():
+    transformers = pytest.importorskip("transformers")
+    from transformers.quantizers.auto import AUTO_QUANTIZATION_CONFIG_MAPPING, AUTO_QUANTIZER_MAPPING
+    assert AUTO_QUANTIZER_MAPPING["flute"] is hf.FluteHfQuantizer
+    assert AUTO_QUANTIZATION_CONFIG_MAPPING["flute"] is hf.FluteConfig
+    cfg = hf.FluteConfig(num_bits=4, group_size=64, num_sms_packed=108, example_batch_size=1)
+    assert hf.FluteConfig.from_dict(cfg.to_dict()).num_sms_packed == 108
+    with pytest.raises(ValueError):
+        hf.FluteConfig(num_bits=5)
+    q = hf.FluteHfQuantizer(cfg, pre_quantized=True)
+    assert q.is_trainable is False and q.is_serializable() is True
+    with pytest.raises(TypeError):
+        q.update_dtype(None)
+    with pytest.raises((NotImplementedError, ValueError)):
+        hf.FluteHfQuantizer(cfg, pre_quantized=False)
+    llama_cfg = transformers.LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=1,
+                                         num_attention_heads=4, num_key_value_heads=4, vocab_size=128)
+    with torch.device("meta"):
+        model = transformers.LlamaForCausalLM(llama_cfg).to(torch.float16)
+    q._process_model_before_weight_loading(model)
+    layer = model.model.layers[0]
+    for lin in (layer.self_attn.q_proj, layer.self_attn.o_proj, layer.mlp.gate_proj, layer.mlp.down_proj):
+        assert isinstance(lin, FluteLinear) and lin.needs_repacking
+    assert not isinstance(model.lm_head, FluteLinear)
+    assert model.config.quantization_config is cfg
+
+
+@pytest.mark.gpu
+def test_checkpoint_packed_for_another_gpu_is_repacked_on_load():
+    """A state dict packed with TileP=64 template ids for a 108-SM GPU loads into the replaced model and is
+    re-laid-out for this GPU: same codes, outputs equal to a model packed natively."""
+    import flute_amd
+    from flute_amd import utils
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dtype, bits, g = torch.float16, 4, 64
+    foreign_tid = 0                                    # b=4: ids with (id % 48) < 16 are TileP = 64
+    assert utils.get_template_config(bits, foreign_tid, 108)["tileP"] == 64
+    table = torch.randn(2 ** bits).to(dtype)
+    ref_model = _Tiny(dtype=dtype)                     # only its shapes and biases are used
+    sd, native = {}, {}
+    for name, mod in ref_model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+            K, N = mod.in_features, mod.out_features
+            codes = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8)
+            scales = (torch.randn(N, K // g) / 8).to(dtype)
+            sd[f"{name}.weight"] = utils.pack(codes, bits, [foreign_tid], 108)
+            sd[f"{name}.scales"] = scales
+            sd[f"{name}.tables"] = table
+            sd[f"{name}.tables2"] = utils.make_qmap2_from_qmap(table)
+            sd[f"{name}._extra_state"] = {"num_bits": bits, "group_size": g, "template_id": foreign_tid}
+            if mod.bias is not None:
+                sd[f"{name}.bias"] = mod.bias.detach().clone()
+            native[name] = (codes, scales)
+    sd["lm_head.weight"] = ref_model.lm_head.weight.detach().clone()
+
+    with torch.device("meta"):
+        model = _Tiny(dtype=dtype)
+    model, replaced = hf.replace_with_flute_linear(model, bits, g)
+    assert replaced
+    model.load_state_dict(sd, assign=True)
+    model = model.to(dev)
+    assert model.layers[0].up_proj.template_id == foreign_tid
+    n = hf.repack_flute_linear(model, num_sms_packed=108, example_batch_size=1)
+    assert n == 4
+
+    x = (torch.randn(3, 512) / 4).to(dtype).to(dev)
+    with torch.no_grad():
+        y = model(x)
+    for name, (codes, scales) in native.items():
+        lin = model.get_submodule(name)
+        assert not lin.needs_repacking
+        got = utils.unpack_codes(lin.weight, bits, lin.template_id).cpu()
+        assert torch.equal(got, codes), name
+        assert torch.equal(lin.tables2.cpu(), utils.make_qmap2_from_qmap(table))
+    # same model built directly for this GPU
+    direct = _Tiny(dtype=dtype).to(dev)
+    for name, (codes, scales) in native.items():
+        bias = sd.get(f"{name}.bias")
+        lin = model.get_submodule(name)
+        new = FluteLinear.from_codes(codes.to(dev), scales.to(dev), table.to(dev), bits, g, lin.template_id,
+                                     bias=None if bias is None else bias.to(dev))
+        parent, leaf = name.rsplit(".", 1)
+        setattr(direct.get_submodule(parent), leaf, new)
+    with torch.no_grad():
+        y_direct = direct(x)
+    assert torch.equal(y, y_direct)
+    assert flute_amd.__name__ == "flute_amd"
