@@ -157,3 +157,46 @@ def test_checkpoint_packed_for_another_gpu_is_repacked_on_load():
         y_direct = direct(x)
     assert torch.equal(y, y_direct)
     assert flute_amd.__name__ == "flute_amd"
+
+
+@pytest.mark.gpu
+def test_transformers_higgs_linear_forward_runs_on_flute_amd():
+    """BASELINE.json configs[4] through its real caller: transformers' `HiggsLinear.forward`
+    (integrations/higgs.py) pads x to the Hadamard block and calls `flute.tune.qgemm_v2(x, weight, scales, tables,
+    tables2.view(float32), workspace, tune_metadata, hadamard_size=...)`, with the buffers produced by
+    `flute.integrations.higgs.prepare_data_transposed`.  transformers binds those names at import time only when a
+    pip-installed `flute` distribution is present, so they are bound by hand here."""
+    pytest.importorskip("transformers")
+    import transformers.integrations.higgs as H
+    import flute_amd
+    from flute_amd import tune, utils
+    from flute_amd.integrations import higgs
+    from oracle import flute_oracle as O
+    H.qgemm_v2, H.TuneMetaData = tune.qgemm_v2, tune.TuneMetaData
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    dtype, bits, g, had, vec = torch.float16, 4, 256, 512, 2
+    K, N = 1024, 512                                               # K a multiple of the Hadamard block
+    layer = H.HiggsLinear(K, N, num_bits=bits, bias=False, dtype=dtype, device=dev, group_size=g,
+                          hadamard_size=had)
+    codes = torch.randint(0, 2 ** (bits * vec), (N, K // vec), dtype=torch.uint8, device=dev)
+    scales = (torch.randn(N, K // g, device=dev) / 4).to(dtype)
+    grid = torch.randn(2 ** (bits * vec), vec, device=dev).to(dtype)
+    Q, S, tables, tables2, meta = higgs.prepare_data_transposed(
+        codes, scales, grid, bits, g, vec, dtype, dev, example_batch_size=1, check_correctness=False)
+    layer.weight.data = Q
+    layer.scales.data = S
+    layer.tables.data = tables
+    layer.tables2.data = tables2.view(dtype=dtype).view(2 ** bits, 2 ** bits, 2)     # how transformers stores it
+    layer.workspace = utils.get_workspace_streamk(dev)
+    layer.tune_metadata = meta
+    x = (torch.randn(5, K, device=dev) / 8).to(dtype)
+    y = layer(x)
+    assert y.shape == (5, N) and y.dtype == dtype
+    # reference: rotate x blockwise, then x @ dequant(W)^T with the vector codebook (tests/higgs.py:7-17)
+    What = O.vector_dequantize_higgs(codes.cpu(), scales.cpu(), grid.cpu())           # [N, K] in T
+    xr = O.hadamard_transform(x.cpu(), had)
+    ref = (xr.double() @ What.double().T)
+    err = ((y.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err < 3e-3, err
+    assert flute_amd.qgemm_hadamard is not None
