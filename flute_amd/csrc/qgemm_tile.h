@@ -342,6 +342,81 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #ifdef FLUTE_STAMPS
         cyc_wait += __builtin_readcyclecounter() - cw0;
 #endif
+#ifndef FLUTE_TILE_NO_BATCH
+        bool batched = false;
+        if constexpr (PRE && R > 1) {
+            // ---- lane-sharing variants (R k-steps per macro-step, J/R column tiles each): a full macro-step
+            // runs as ONE dependent chain - every word/activation read, then every pair lookup, then the
+            // multiplies and MFMAs - instead of R chains of (read, wait, lookup, wait, multiply, MFMA); no
+            // branch between the reads.  A ragged last macro-step takes the k-step loop below. ----
+            if ((t + 1) * R <= nsteps) {
+                batched = true;
+                uint32_t sc[R][NMF];
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const int grp = (kb + (t * R + s) * 32) >> lg;
+                    if (grp != cur_group) {
+                        const int blk = grp >> 3;
+                        if (cur_group < 0 || blk != (cur_group >> 3)) {   // entering a scale block (see below)
+                            if (sdma) {
+                                if (cur_group >= 0 && t - t_sc < D) vm_wait<0>();
+                                if (blk < blk_last) { issue_scales(blk + 1); t_sc = t; }
+                            } else if (cur_group >= 0) {
+                                sync_scales(blk);
+                            }
+                        }
+                        const uint32_t sb = sc_base + (uint32_t)(blk & 1) * SBUF + (uint32_t)(grp & 7) * 2;
+#pragma unroll
+                        for (int i = 0; i < NMF; ++i)
+                            sreg[i] = *reinterpret_cast<const uint16_t*>(smem + sb + (uint32_t)(i * 16 + r16) * 16);
+                        cur_group = grp;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i) sc[s][i] = sreg[i];     // in registers: the block buffer may be refilled
+                }
+                uint32_t qw[R][4];
+                u32x4_t af[R][MT];
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    const uint4 v = lds_ld128(slot + qread + (uint32_t)(((s * 4 + q4) ^ qswz) * 16));
+                    qw[s][0] = v.x; qw[s][1] = v.y; qw[s][2] = v.z; qw[s][3] = v.w;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const uint4 x = lds_ld128(slot + (QP + s * MT + mt) * 1024 + aread);
+                        af[s][mt] = u32x4_t{x.x, x.y, x.z, x.w};
+                    }
+                }
+                const bool refill = (t + D < nmacro);
+                if (refill) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of the slot has returned
+#pragma unroll
+                    for (int P = 0; P < LPS; ++P) issue_piece(P, kb + (t + D) * (32 * R), slot);
+                }
+                uint32_t lut[R][NMF][4];
+#pragma unroll
+                for (int s = 0; s < R; ++s)
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i)
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) {
+                            const uint32_t idx = __builtin_amdgcn_ubfe(qw[s][ww], (uint32_t)(2 * BITS) * (uint32_t)(i * R + f),
+                                                                       (uint32_t)(2 * BITS));
+                            lut[s][i][ww] = lds_ld32((idx << TILE_LUT_SHIFT) | lane_off);
+                        }
+#pragma unroll
+                for (int s = 0; s < R; ++s)
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i) {
+                        u32x4_t bf;
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) bf[ww] = NT::mul_scale(lut[s][i][ww], sc[s][i]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][i] = Mfma<T>::run(bf, af[s][mt], acc[mt][i]);
+                    }
+            }
+        }
+        if (!batched)
+#endif
 #pragma unroll
         for (int s = 0; s < R; ++s) {
             const int ks = t * R + s;

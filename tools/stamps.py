@@ -38,7 +38,10 @@ cases = [
     (4096, 4096, 4096, (FAM, 1, 8, 1, 1, 4, -1)),
 ]
 out = []
+ONLY_M = int(os.environ.get("STAMPS_ONLY_M", "0"))     # restrict to one batch size (ablation passes)
 for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
+    if ONLY_M and M != ONLY_M:
+        continue
     lay = bench.Layer(M, N, K, 4, 64, f16, dev, 2)
     lay.template_id = 16
     lib.flute_set_overrides(*ovr)

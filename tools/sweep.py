@@ -180,6 +180,19 @@ elif which == "w4":         # fewer, fatter waves: less launch skew, less latenc
         run(1, 4096, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
     for waves, kw in ((16, 1), (4, 1), (4, 2), (4, 4), (8, 1)):
         run(1, 11008, 4096, 4, 64, f16, 16, (0, -1, waves, kw, 1, -1, 0))
+elif which == "batch":      # lane-sharing (R > 1) tile kernels: batched macro-step vs -DFLUTE_TILE_NO_BATCH
+    for R in (4, 2):
+        run(16, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 1, -1))
+        run(16, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 4, 1, 1, -1))
+        run(16, 11008, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 1, -1))
+        run(16, 28672, 8192, 4, 64, f16, 16, (2, R, 8, 8, 1, 1, -1), steps=100)
+        run(32, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 2, -1))
+        run(64, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 4, -1))
+    run(8, 4096, 4096, 4, 64, f16, 16, (2, 4, 8, 8, 1, 1, -1))
+    run(16, 4096, 4096, 2, 64, f16, 4, (2, 4, -1, -1, -1, -1, -1))
+    run(16, 8192, 8192, 4, 128, f16, 16, (2, 4, 8, 8, 1, 1, -1))
+    run(16, 4096, 4096, 4, 64, f16, 16, (-1, -1, -1, -1, -1, -1, -1))
+    run(16, 11008, 4096, 4, 64, f16, 16, (-1, -1, -1, -1, -1, -1, -1))
 elif which == "ring":
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 16, 1, 1, -1, 0), steps=100)
     run(1, 28672, 8192, 4, 64, f16, 16, (0, -1, 8, 1, 1, -1, 0), steps=100)
