@@ -155,7 +155,8 @@ def cpu_baseline(N, K, bits, g, tile_p=32, runs=36):
     W = rng.integers(0, 2 ** bits, size=(K, N), dtype=np.uint8)
     Q = O.pack(W, bits, tile_p)
     S = torch.randn(N, K // g).to(dtype)
-    table = torch.tensor(O.NF4_VALUES).to(dtype)
+    from flute_amd.nf_utils import NF4_VALUES
+    table = torch.tensor(NF4_VALUES).to(dtype)
     X = (torch.randn(1, K) / 100).to(dtype)
     t0 = time.perf_counter()
     codes = torch.from_numpy(O.unpack(Q, bits, tile_p).astype(np.int64))
@@ -267,7 +268,7 @@ def main():
         def sync():
             torch.cuda.synchronize()
 
-    from oracle.flute_oracle import NF4_VALUES
+    from flute_amd.nf_utils import NF4_VALUES        # the oracle is imported by the cpu_baseline leg only
     M, N, K, bits, g, dtype = 1, 4096, 4096, 4, 64, torch.float16
     layer = Layer(M, N, K, bits, g, dtype, device, copies_for(N, K, bits), NF4_VALUES, seed=rank)
     if args.template_id >= 0:

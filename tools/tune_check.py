@@ -5,7 +5,7 @@ from flute_amd import utils
 dev = torch.device("cuda:0")
 for M in (8, 32, 64, 128):
     for (n, k) in ((4096, 4096), (11008, 4096)):
-        lay = bench.Layer(M, n, k, 4, 64, torch.float16, dev, bench.copies_for(n, k, 4), bench.NF4_VALUES if hasattr(bench, "NF4_VALUES") else None)
+        lay = bench.Layer(M, n, k, 4, 64, torch.float16, dev, bench.copies_for(n, k, 4), None)
         tid = lay.tune()
         ms, _ = bench.time_graph(lay, 300, 20, torch.cuda.synchronize)
         p = utils.get_plan(M, n, k, 4, 64, tid, lay.num_sms, torch.float16)
