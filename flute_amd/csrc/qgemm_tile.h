@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #endif
 #ifndef FLUTE_TILE_NO_BATCH
         bool batched = false;
-        if constexpr (PRE && R > 1) {
+        if constexpr (R > 1) {
             // ---- lane-sharing variants (R k-steps per macro-step, J/R column tiles each): a full macro-step
             // runs as ONE dependent chain - every word/activation read, then every pair lookup, then the
             // multiplies and MFMAs - instead of R chains of (read, wait, lookup, wait, multiply, MFMA); no
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
             if ((t + 1) * R <= nsteps) {
                 batched = true;
                 uint32_t sc[R][NMF];
+                if constexpr (PRE) {
 #pragma unroll
                 for (int s = 0; s < R; ++s) {
                     const int grp = (kb + (t * R + s) * 32) >> lg;
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                     }
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) sc[s][i] = sreg[i];     // in registers: the block buffer may be refilled
+                }
                 }
                 uint32_t qw[R][4];
                 u32x4_t af[R][MT];
@@ -404,15 +406,37 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                             lut[s][i][ww] = lds_ld32((idx << TILE_LUT_SHIFT) | lane_off);
                         }
 #pragma unroll
-                for (int s = 0; s < R; ++s)
+                for (int s = 0; s < R; ++s) {
+                    if constexpr (!PRE) {
+                        // bf16: group bookkeeping between the MFMAs, in the k-step loop's order (fold the finished
+                        // group's run, then request the next scale block); the reads and lookups are already out
+                        const int grp = (kb + (t * R + s) * 32) >> lg;
+                        if (grp != cur_group) {
+                            if (cur_group >= 0) fold_run(cur_group);
+                            const int blk = grp >> 3;
+                            if (cur_group < 0 || blk != (cur_group >> 3)) {
+                                if (sdma) {
+                                    if (cur_group >= 0 && t - t_sc < D) vm_wait<0>();
+                                    if (blk < blk_last) { issue_scales(blk + 1); t_sc = t; }
+                                } else if (cur_group >= 0) {
+                                    sync_scales(blk);
+                                }
+                            }
+                            cur_group = grp;
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         u32x4_t bf;
 #pragma unroll
-                        for (int ww = 0; ww < 4; ++ww) bf[ww] = NT::mul_scale(lut[s][i][ww], sc[s][i]);
+                        for (int ww = 0; ww < 4; ++ww) bf[ww] = PRE ? NT::mul_scale(lut[s][i][ww], sc[s][i]) : lut[s][i][ww];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][i] = Mfma<T>::run(bf, af[s][mt], acc[mt][i]);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if constexpr (PRE) acc[mt][i] = Mfma<T>::run(bf, af[s][mt], acc[mt][i]);
+                            else run[mt][i] = Mfma<T>::run(bf, af[s][mt], run[mt][i]);
+                        }
                     }
+                }
             }
         }
         if (!batched)

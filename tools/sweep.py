@@ -189,6 +189,10 @@ elif which == "batch":      # lane-sharing (R > 1) tile kernels: batched macro-s
         run(32, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 2, -1))
         run(64, 4096, 4096, 4, 64, f16, 16, (2, R, 8, 8, 1, 4, -1))
     run(8, 4096, 4096, 4, 64, f16, 16, (2, 4, 8, 8, 1, 1, -1))
+    for R, MT in ((4, 1), (2, 1), (2, 2)):
+        run(16 * MT, 4096, 4096, 4, 64, bf16, 16, (2, R, 8, 8, 1, MT, -1))
+    run(16, 11008, 4096, 4, 64, bf16, 16, (2, 2, 8, 8, 1, 1, -1))
+    run(16, 8192, 8192, 4, 128, bf16, 16, (2, 4, 8, 8, 1, 1, -1))
     run(16, 4096, 4096, 2, 64, f16, 4, (2, 4, -1, -1, -1, -1, -1))
     run(16, 8192, 8192, 4, 128, f16, 16, (2, 4, 8, 8, 1, 1, -1))
     run(16, 4096, 4096, 4, 64, f16, 16, (-1, -1, -1, -1, -1, -1, -1))
