@@ -42,13 +42,14 @@ ONLY_M = int(os.environ.get("STAMPS_ONLY_M", "0"))     # restrict to one batch s
 for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
     if ONLY_M and M != ONLY_M:
         continue
-    lay = bench.Layer(M, N, K, 4, 64, f16, dev, 2)
+    COLD = os.environ.get("STAMPS_COLD") == "1"      # rotate over > 256 MiB of weight copies: the stamped launch reads HBM
+    lay = bench.Layer(M, N, K, 4, 64, f16, dev, bench.copies_for(N, K, 4) if COLD else 2)
     lay.template_id = 16
     lib.flute_set_overrides(*ovr)
     plan = utils.get_plan(M, N, K, 4, 64, 16, lay.num_sms, f16)
     nwaves = plan["grid"] * plan["waves"]
     ws64 = lay.ws.view(torch.int64)
-    for i in range(3):
+    for i in range(len(lay.Q) if COLD else 3):
         lay.step(i)
     torch.cuda.synchronize()
     ws64[: nwaves * 8].zero_()
