@@ -246,6 +246,16 @@ FULL_SHAPES = [
     (3, 32, 64, torch.bfloat16, 8192, 8192),
     (4, 32, 64, torch.float16, 8192, 3584),      # TP=8 column shard of 8192x28672
     (2, 64, 128, torch.bfloat16, 4096, 4096),
+    # Llama-3-70B linear shapes of the reference's tests/shapes.py:9-15 (BASELINE configs[2], [3])
+    (3, 32, 64, torch.bfloat16, 8192, 28672),
+    (3, 32, 64, torch.bfloat16, 28672, 8192),    # K = 28672: activations staged in K chunks at M = 4
+    (3, 32, 64, torch.bfloat16, 8192, 10240),
+    (3, 32, 64, torch.bfloat16, 8192, 1024),     # narrow: grid-level K split
+    (4, 32, 64, torch.float16, 8192, 28672),
+    (4, 64, 64, torch.float16, 28672, 8192),
+    # Gemma-2-9B (configs[4]; tests/shapes.py:53-61)
+    (4, 32, 64, torch.float16, 3584, 14336),
+    (4, 32, 64, torch.float16, 14336, 3584),
 ]
 
 
