@@ -3,7 +3,7 @@
 // qgemm_kernel_raw_generated.cu:15-768 (_qgemm_raw's template switch) +
 // qgemm_kernel.hpp:824-939 (qgemm_host), re-thought for gfx950: instead of one
 // Stream-K kernel with 36/144 tile variants there are two kernel families
-// (streaming decode for M <= 8, MFMA above) whose launch geometry is derived
+// (streaming decode for M <= 4 - 3-bit: M <= 2 -, MFMA above) whose launch geometry is derived
 // from the template's knobs and the problem shape.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -81,9 +81,6 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     const int lines = K / 64;
 
     memset(p, 0, sizeof(*p));
-    int copies = g_ovr.lut_copies > 0 ? g_ovr.lut_copies : t.lut_copies;
-    if (copies != 1 && copies != 8 && copies != 16 && copies != 32) copies = 32;
-    p->lut_copies = copies;
 
     const int dec_max = (bits == 3) ? 2 : 4;
     int family = (M <= dec_max) ? 0 : 2;
