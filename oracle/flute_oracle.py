@@ -21,6 +21,11 @@ Pinning status
 * hadamard: PARITY UNPINNED.  No reference test exercises
   `hadamard_transform` / `qgemm_hadamard`; the oracle is the mathematical
   definition (orthonormal Sylvester Hadamard, `hadamard_transform_cuda.cu:141-154`).
+  `hadamard_transform_staged` additionally emulates the reference kernel's STAGED
+  arithmetic (one 16x16 factor per tensor-core pass, every pass rounded to T, the
+  scale constants rounded to T - `hadamard_transform_cuda.cu:56-73,141-154`), so
+  that tests can report how far the HIP kernel (fp32 butterflies, one rounding)
+  is from what the CUDA kernel would return.
 
 Notation (the reference's): W[K,N] integer codes, Q[P,K] int16 packed,
 S[N,G] scales, table[2^b], table2[2^b,2^b,1] fp32-viewed pair table, X[M,K].
@@ -254,6 +259,40 @@ def hadamard_transform(X: torch.Tensor, had_size: int) -> torch.Tensor:
     (qgemm.cpp:201-211; hadamard_transform.cpp:17-56)."""
     flat = X.reshape(-1, had_size).double()
     return (flat @ hadamard_matrix(had_size)).to(X.dtype).reshape(X.shape)
+
+
+def hadamard_transform_staged(X: torch.Tensor, had_size: int) -> torch.Tensor:
+    """Emulation of the reference kernel's arithmetic (hadamard_transform_cuda.cu).
+
+    HadaCore factors H_h = H_16 (x) ... (x) H_16 (x) H_{2^r} and applies one factor per
+    tensor-core pass: `mma.m16n8k16` with the factor matrix held as +-c constants, c =
+    2^(-bits/2) ROUNDED TO T (fp16 0x39A8 / bf16 0x3F35 = 0.70703125 for odd `bits`, :141-154),
+    fp16: f16 accumulate (:56), bf16: f32 accumulate then cvt.rn.bf16x2 (:62-69) - i.e. every
+    pass ends with a rounding to T.  Emulated as: per pass, exact products summed in fp32,
+    rounded to T once (an upper bound on the precision of the f16-accumulating mma).  The
+    passes act on successive 4-bit digit groups of the index, low digits first; the order does
+    not change the mathematical result, only which partial sums are rounded.
+    """
+    dtype = X.dtype
+    log_h = had_size.bit_length() - 1
+    if had_size < 1 or (1 << log_h) != had_size:
+        raise ValueError(had_size)
+    flat = X.reshape(-1, had_size)
+    rows = flat.shape[0]
+    bits_done = 0
+    cur = flat
+    factors = [4] * (log_h // 4) + ([log_h % 4] if log_h % 4 else [])
+    for fb in factors:
+        n = 1 << fb
+        c = torch.tensor(2.0 ** (-fb / 2)).to(dtype).float()            # scale constant in T
+        Hf = (hadamard_matrix(n) * (n ** 0.5)).float() * c              # +-c entries
+        lo = 1 << bits_done
+        hi = had_size // (lo * n)
+        t = cur.float().reshape(rows, hi, n, lo)
+        t = torch.einsum("rhnl,nm->rhml", t, Hf)
+        cur = t.reshape(rows, had_size).to(dtype)                       # rounding of this pass
+        bits_done += fb
+    return cur.reshape(X.shape)
 
 
 def qgemm_hadamard(X, Q, S, table, table2, num_bits, group_size, hadamard_size, tile_p):
