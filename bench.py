@@ -76,6 +76,7 @@ class Layer:
         self.qgemm = flute_amd.qgemm
         self.hadamard_size = hadamard_size      # > 0: flute.qgemm_hadamard (rotation fused into the decode kernel)
         self.qgemm_hadamard = flute_amd.qgemm_hadamard
+        self.ovr = None                         # development sweeps: per-call plan override (flute_amd.dev.Overrides)
 
     def bytes(self):
         return algorithmic_bytes(self.M, self.N, self.K, self.bits, self.g)
@@ -91,6 +92,10 @@ class Layer:
 
     def step(self, i):
         c = i % len(self.Q)
+        if self.ovr is not None:
+            from flute_amd import dev
+            return dev.qgemm_planned(self.X, self.Q[c], self.S[c], self.table, self.table2, self.ws, self.bits,
+                                     self.g, self.template_id, self.num_sms, self.ovr, self.hadamard_size)
         if self.hadamard_size:
             return self.qgemm_hadamard(self.X, self.Q[c], self.S[c], self.table, self.table2, self.ws,
                                        self.bits, self.g, self.hadamard_size, self.template_id, self.num_sms)

@@ -25,10 +25,21 @@ class Plan(ctypes.Structure):
         ("kw", c_int),
         ("splitk", c_int), ("k_per_split", c_int), ("lut_copies", c_int),
         ("grid", ctypes.c_uint), ("block", ctypes.c_uint),
-        ("lds_bytes", c_size_t), ("workspace_needed", c_size_t)]
+        ("lds_bytes", c_size_t), ("workspace_needed", c_size_t),
+        ("ring_depth", c_int), ("visits", c_int), ("k_chunks", c_int), ("reserved", c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Overrides(ctypes.Structure):
+    """Per-call launch-plan overrides (include/flute_amd.h `flute_overrides`); -1 = automatic."""
+    _fields_ = [(n, c_int) for n in (
+        "family", "m_block", "waves", "kw", "splitk", "m_tiles", "slabs_per_wave", "ring_depth")]
+
+    def __init__(self, family=-1, m_block=-1, waves=-1, kw=-1, splitk=-1, m_tiles=-1, slabs_per_wave=-1,
+                 ring_depth=-1):
+        super().__init__(family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth)
 
 
 # every symbol include/flute_amd.h declares: name -> (restype, argtypes)
@@ -37,12 +48,14 @@ SYMBOLS = {
     "flute_strerror": (c_char_p, [c_int]),
     "flute_num_templates": (c_int, [c_int]),
     "flute_get_template_info": (c_int, [c_int, c_int, ctypes.POINTER(TemplateInfo)]),
-    "flute_set_overrides": (None, [c_int] * 7),
     "flute_qgemm_plan": (c_int, [c_int] * 8 + [c_size_t, ctypes.POINTER(Plan)]),
+    "flute_qgemm_plan_ex": (c_int, [c_int] * 8 + [c_size_t, ctypes.POINTER(Overrides), ctypes.POINTER(Plan)]),
+    "flute_qgemm_ex": (c_int, [c_int] * 8 + [c_void_p] * 8 + [c_size_t, c_int, c_int, ctypes.POINTER(Overrides),
+                               c_void_p]),
     "flute_qgemm": (c_int, [c_int] * 7 + [c_void_p] * 7 + [c_size_t, c_int, c_int, c_void_p]),
     "flute_qgemm_hadamard": (c_int, [c_int] * 8 + [c_void_p] * 8 + [c_size_t, c_int, c_int, c_void_p]),
     "flute_qgemm_hadamard_fused": (c_int, [c_int] * 9 + [c_size_t]),
-    "flute_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
+    "flute_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
     "flute_unpack": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flute_debug_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
 }
@@ -63,7 +76,7 @@ def get() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.flute_abi_version() != 2:
+        if lib.flute_abi_version() != 3:
             raise ImportError("flute_amd: ABI version mismatch, rebuild libflute_amd.so")
         _lib = lib
     return _lib

@@ -4,16 +4,20 @@
 // qgemm_kernel.hpp:824-939 (qgemm_host), re-thought for gfx950: instead of one
 // Stream-K kernel with 36/144 tile variants there are two kernel families
 // (streaming decode for M <= 4 - 3-bit: M <= 2 -, MFMA above) whose launch geometry is derived
-// from the template's knobs and the problem shape.
+// from the template's knobs and the problem shape.  Nothing here is process-global mutable state
+// except the per-device "large LDS granted" cache (mutex-guarded): plan overrides travel with the call.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <mutex>
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/flute_amd.h"
 #include "kernels.h"
 #include "qgemm_decode.h"
+#include "qgemm_stream.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
 
@@ -21,10 +25,14 @@ using namespace flute_amd;
 
 namespace {
 
-struct Overrides { int family, m_block, waves, kw, splitk, lut_copies, prescale; };
-Overrides g_ovr = {-1, -1, -1, -1, -1, -1, -1};
+struct Ovr { int family, m_block, waves, kw, splitk, m_tiles, slabs, depth; };
+Ovr ovr_of(const flute_overrides* o) {
+    if (!o) return Ovr{-1, -1, -1, -1, -1, -1, -1, -1};
+    return Ovr{o->family, o->m_block, o->waves, o->kw, o->splitk, o->m_tiles, o->slabs_per_wave, o->ring_depth};
+}
 
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kFamilyLegacyDecode = 4;          // round-1 decode kernel, reachable by override only (A/B runs)
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
@@ -58,13 +66,203 @@ bool decode_template(int bits, int id, flute_template_info* t) {
     t->tile_k = 64;
     t->tile_p = kTileP[tile];
     t->stages = 2 + st;
-    // b=2/3 pair tables are 64 B / 256 B: always replicate them 32x
+    // the reference's QuantMapMode slot; b=2/3 templates have none
     t->lut_copies = (bits == 4) ? kCopies[q] : 32;
     return true;
 }
 
+// ---- streaming decode kernel: launch shape ------------------------------------------------------------
+// Every (waves per workgroup, in-workgroup K split) that fits LDS is priced by the piece-slots its busiest
+// CU executes (1 piece = 1 KiB of one unit's packed row) plus a per-visit overhead, and the candidates are
+// ranked; template knob Stages (2..5) picks the best / 2nd / 3rd / 4th, so the tuner's search over ids
+// covers the shapes that matter.
+struct StreamShape {
+    int W, kw, nchunks, kc, kx, upw, ngroups, nwg, visits, s_wave_bytes, s_fast;
+    size_t x_off, s_off, red_off, total;
+    double cost;
+};
+
+bool stream_shape(int bits, int mb, int lg, int units, int krange, int G, bool split_aligned, int num_sms, int W,
+                  int kw, int threads_cap, StreamShape* o) {
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int g = 1 << lg;
+    const int gpp = 512 >> lg;
+    const int lut = stream_lut_bytes(bits);
+    const int align_k = std::max(512, 8 * g);                 // K boundaries on 16-B scale granules
+    StreamShape s;
+    s.W = W; s.kw = kw;
+    s.upw = W / kw;
+    s.ngroups = ceil_div(units, s.upw);
+    bool fits = false;
+    for (int nch = 1; nch <= 64; ++nch) {
+        int kc = (nch == 1) ? round_up(krange, 512) : round_up(ceil_div(krange, nch), align_k);
+        const int real_chunks = ceil_div(krange, kc);
+        if (nch > 1 && real_chunks != nch) continue;
+        const int pc = ceil_div(std::min(kc, krange), 512);
+        const int pk = ceil_div(pc, kw);
+        const int ngran = ceil_div(pk * gpp, 8);
+        s.s_wave_bytes = ngran * J * 16;
+        s.kx = round_up(std::min(kc, krange), 512);
+        s.x_off = (size_t)lut;
+        s.s_off = s.x_off + (size_t)mb * s.kx * 2;
+        s.red_off = s.s_off + (size_t)W * s.s_wave_bytes;
+        s.total = s.red_off + (size_t)2 * W * J * mb * 4;
+        if (s.total <= (size_t)kMaxLds) {
+            s.nchunks = nch; s.kc = kc;
+            const bool chunk_ok = nch == 1 || kc % (8 * g) == 0;
+            const bool part_ok = kw == 1 || (pk * 512) % (8 * g) == 0;
+            s.s_fast = (G % 8 == 0 && split_aligned && chunk_ok && part_ok) ? 1 : 0;
+            const int occ = (threads_cap >= 1024 && W <= 8 && s.total <= (size_t)kMaxLds / 2) ? 2 : 1;
+            s.nwg = std::min(s.ngroups, num_sms * occ);
+            s.visits = ceil_div(s.ngroups, s.nwg);
+            const int wgs_cu = ceil_div(s.nwg, num_sms);
+            const double per_visit = pk + 1.5 + (kw > 1 ? 2.0 : 0.0) + (s.s_fast ? 0.0 : 4.0);
+            double cost = (double)wgs_cu * W * s.visits * nch * per_visit;
+            const int waves_cu = wgs_cu * W;
+            if (waves_cu < 12) cost *= 1.0 + 0.05 * (12 - waves_cu);   // fewer bytes in flight per CU
+            if (nch > 1) cost *= 1.25;                        // activations restaged per visit, barriers
+            s.cost = cost;
+            fits = true;
+            break;
+        }
+    }
+    if (!fits) return false;
+    *o = s;
+    return true;
+}
+
+int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
+                const Ovr& ov, size_t workspace_bytes, flute_plan* p, StreamArgs* sa) {
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int units = N / J;
+    const int G = K >> lg;
+    int mb = 1; while (mb < M) mb <<= 1;
+    const int dec_max = (bits == 3) ? 2 : 4;
+    if (ov.m_block > 0 && ov.m_block >= M && ov.m_block <= dec_max) mb = floor_pow2(ov.m_block);
+    int depth = (bits == 3) ? 2 : (t.sms_multiple == 1 ? 4 : 2);
+    if (ov.depth == 2 || (ov.depth == 4 && bits != 3)) depth = ov.depth;
+    const int threads_cap = std::min(t.threads, stream_max_threads(bits, mb, depth));
+    const int wcap = threads_cap / 64;
+
+    // grid-level K split only for layers too narrow to give every CU eight waves even at the deepest
+    // in-workgroup split
+    int splitk = 1;
+    while ((long)units * 16 * splitk < (long)num_sms * 8 && K / (splitk * 2) >= 1024) splitk *= 2;
+    if (ov.splitk > 0) splitk = ov.splitk;
+    const int align_k = std::max(512, 8 << lg);
+    int kps = round_up(ceil_div(K, splitk), align_k);
+    splitk = ceil_div(K, kps);
+    while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+        splitk >>= 1;
+        kps = round_up(ceil_div(K, splitk), align_k);
+        splitk = ceil_div(K, kps);
+    }
+    if (splitk == 1) kps = round_up(K, 512);
+    const int krange = std::min(K, kps);
+    const bool split_aligned = splitk == 1 || kps % (8 << lg) == 0;
+
+    std::vector<StreamShape> cands;
+    for (int W = 1; W <= wcap; ++W) {
+        if (ov.waves > 0 && W != std::min(ov.waves, wcap)) continue;
+        for (int kw = 1; kw <= W; kw <<= 1) {
+            if (W % kw) continue;
+            if (ov.kw > 0 && kw != std::min(floor_pow2(ov.kw), floor_pow2(W))) continue;
+            StreamShape s;
+            if (stream_shape(bits, mb, lg, units, krange, G, split_aligned, num_sms, W, kw, threads_cap, &s))
+                cands.push_back(s);
+        }
+    }
+    if (cands.empty()) return FLUTE_ERR_SHAPE;
+    // shapes of fewer than 8 waves are only worth ranking when nothing larger exists
+    if (ov.waves <= 0) {
+        const int wmin = std::min(8, wcap);
+        bool any = false;
+        for (const StreamShape& c : cands) any = any || c.W >= wmin;
+        if (any) cands.erase(std::remove_if(cands.begin(), cands.end(), [&](const StreamShape& c) { return c.W < wmin; }),
+                             cands.end());
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const StreamShape& a, const StreamShape& b) {
+        if (a.cost != b.cost) return a.cost < b.cost;
+        if (a.W != b.W) return a.W > b.W;
+        return a.kw < b.kw;
+    });
+    // Stages 2..5 -> rank 0..3 among shapes that differ in (W, kw); explicit overrides leave one candidate
+    size_t pick = std::min((size_t)std::max(0, t.stages - 2), cands.size() - 1);
+    if (ov.waves > 0 || ov.kw > 0) pick = 0;
+    const StreamShape& s = cands[pick];
+
+    p->family = 0;
+    p->m_block = mb; p->waves = s.W; p->kw = s.kw; p->splitk = splitk;
+    p->k_per_split = (splitk == 1) ? K : kps;
+    p->grid = (unsigned)(s.nwg * splitk);
+    p->block = (unsigned)(s.W * 64);
+    p->lds_bytes = s.total;
+    p->lut_copies = 32;
+    p->ring_depth = depth; p->visits = s.visits; p->k_chunks = s.nchunks;
+    if (sa) {
+        memset(sa, 0, sizeof(*sa));
+        sa->M = M; sa->N = N; sa->K = K; sa->G = G; sa->lg = lg;
+        sa->units = units; sa->ngroups = s.ngroups;
+        sa->upw = s.upw; sa->kw = s.kw; sa->lkw = ilog2(s.kw);
+        sa->nwg = s.nwg; sa->vis_q = s.ngroups / s.nwg; sa->vis_r = s.ngroups % s.nwg;
+        sa->splitk = splitk; sa->k_per_split = kps;
+        sa->kc = s.kc; sa->nchunks = s.nchunks; sa->kx = s.kx;
+        sa->x_off = (int)s.x_off; sa->s_off = (int)s.s_off; sa->red_off = (int)s.red_off;
+        sa->s_wave_bytes = s.s_wave_bytes; sa->s_fast = s.s_fast;
+    }
+    (void)dtype;
+    return FLUTE_OK;
+}
+
+// round-1 decode kernel (qgemm_decode.h), kept for A/B measurements: override family = 4
+int plan_legacy_decode(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
+                       const Ovr& ov, size_t workspace_bytes, flute_plan* p) {
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int units = N / J, lines = K / 64;
+    const int dec_max = (bits == 3) ? 2 : 4;
+    int mb = 1; while (mb < M) mb <<= 1;
+    if (ov.m_block > 0 && ov.m_block >= M && ov.m_block <= dec_max) mb = ov.m_block;
+    int waves = t.threads / 64;
+    if (ov.waves > 0) waves = floor_pow2(ov.waves);
+    if (waves > dec_max_threads(bits, mb) / 64) waves = dec_max_threads(bits, mb) / 64;
+    if (waves < 1) waves = 1;
+    const long target_waves = (long)num_sms * t.sms_multiple * waves;
+    int f = 1;
+    while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
+    int kw = f < waves ? f : waves;
+    int splitk = f / kw;
+    if (ov.kw > 0) kw = floor_pow2(ov.kw);
+    if (ov.splitk > 0) splitk = ov.splitk;
+    if (kw > waves) kw = waves;
+    while (waves % kw) kw >>= 1;
+    while ((units % (waves / kw)) && kw < waves) kw <<= 1;
+    int kps = round_up(ceil_div(K, splitk), 512);
+    splitk = ceil_div(K, kps);
+    while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+        splitk >>= 1;
+        kps = round_up(ceil_div(K, splitk), 512);
+        splitk = ceil_div(K, kps);
+    }
+    if (splitk == 1) kps = K;
+    const DecodeGeom geo = decode_geom(bits, mb, lg, waves, kw, kps, kMaxLds);
+    const int ngroups = units / (waves / kw);
+    int occ = (int)(kMaxLds / geo.total);
+    if (occ > 2048 / (waves * 64)) occ = 2048 / (waves * 64);
+    if (occ < 1) occ = 1;
+    long nwg = (long)num_sms * occ;
+    if (nwg > ngroups) nwg = ngroups;
+    p->family = kFamilyLegacyDecode;
+    p->m_block = mb; p->waves = waves; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
+    p->grid = (unsigned)(nwg * splitk);
+    p->block = (unsigned)(waves * 64);
+    p->lds_bytes = geo.total;
+    p->lut_copies = (bits == 4) ? 64 : 32;
+    return FLUTE_OK;
+}
+
 int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
-              size_t workspace_bytes, flute_plan* p, flute_template_info* tinfo) {
+              size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
+              StreamArgs* sa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
     if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
     if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
@@ -78,60 +276,20 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     if (num_sms < 1) num_sms = 256;
     const int lg = ilog2(group);
     const int units = N / J;
-    const int lines = K / 64;
 
     memset(p, 0, sizeof(*p));
 
     const int dec_max = (bits == 3) ? 2 : 4;
     int family = (M <= dec_max) ? 0 : 2;
-    if (g_ovr.family == 0 && M <= dec_max) family = 0;
-    if (g_ovr.family >= 1) family = 2;            // any M may be forced through the MFMA kernel
+    if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
+    else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
     p->family = family;
 
+    int rc = FLUTE_OK;
     if (family == 0) {
-        int mb = 1; while (mb < M) mb <<= 1;
-        if (g_ovr.m_block > 0 && g_ovr.m_block >= M && g_ovr.m_block <= dec_max) mb = g_ovr.m_block;
-        int waves = t.threads / 64;
-        if (g_ovr.waves > 0) waves = floor_pow2(g_ovr.waves);      // the kernels shift by log2(waves), log2(kw)
-        if (waves > dec_max_threads(bits, mb) / 64) waves = dec_max_threads(bits, mb) / 64;
-        if (waves < 1) waves = 1;
-        // K split so that the chip holds >= num_sms * mult workgroups' worth of waves; every
-        // octet of a wave keeps at least one 64-k line
-        const long target_waves = (long)num_sms * t.sms_multiple * waves;
-        int f = 1;
-        while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
-        int kw = f < waves ? f : waves;
-        int splitk = f / kw;
-        // Stages (2..5) has no pipeline to size here: the tuner uses it to try the neighbouring
-        // K splits (same, half, double, quadruple)
-        if (t.stages == 3 && kw > 1) kw >>= 1;
-        if (t.stages == 4) kw <<= 1;
-        if (t.stages == 5) kw <<= 2;
-        if (g_ovr.kw > 0) kw = floor_pow2(g_ovr.kw);
-        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
-        if (kw > waves) kw = waves;
-        while (waves % kw) kw >>= 1;
-        while ((units % (waves / kw)) && kw < waves) kw <<= 1;
-        int kps = round_up(ceil_div(K, splitk), 512);
-        splitk = ceil_div(K, kps);
-        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
-            splitk >>= 1;
-            kps = round_up(ceil_div(K, splitk), 512);
-            splitk = ceil_div(K, kps);
-        }
-        if (splitk == 1) kps = K;
-        const DecodeGeom geo = decode_geom(bits, mb, lg, waves, kw, kps, kMaxLds);
-        const int ngroups = units / (waves / kw);
-        int occ = (int)(kMaxLds / geo.total);
-        if (occ > 2048 / (waves * 64)) occ = 2048 / (waves * 64);
-        if (occ < 1) occ = 1;
-        long nwg = (long)num_sms * occ;
-        if (nwg > ngroups) nwg = ngroups;
-        p->m_block = mb; p->waves = waves; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
-        p->grid = (unsigned)(nwg * splitk);
-        p->block = (unsigned)(waves * 64);
-        p->lds_bytes = geo.total;
-        p->lut_copies = (bits == 4) ? 64 : 32;
+        rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
+    } else if (family == kFamilyLegacyDecode) {
+        rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else {
         // M > decode range: MFMA kernel (qgemm_tile.h).  MT 16-row tiles per wave (1 for M <= 16),
         // R lanes share a unit: pick the smallest R whose slab x row-tile count fills the chip; the
@@ -144,7 +302,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         // SMs_Multiple = "more, smaller workgroups": halves / quarters the row tiles per wave (and,
         // below, raises the slab count the choice of R aims for)
         for (int m2 = t.sms_multiple; m2 > 1 && mt > 1; m2 >>= 1) mt >>= 1;
-        if (g_ovr.lut_copies == 1 || g_ovr.lut_copies == 2 || g_ovr.lut_copies == 4) mt = g_ovr.lut_copies;
+        if (ov.m_tiles == 1 || ov.m_tiles == 2 || ov.m_tiles == 4) mt = ov.m_tiles;
         if (mt > mt_cap) mt = mt_cap;
         // instantiated (R, MT): (J/R)*MT <= 16 accumulator tiles, R in {1,2,4}, MT > 1 needs R <= 2
         auto combo_ok = [&](int r, int m) {
@@ -156,7 +314,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         int R = 1;
         while (!combo_ok(R, mt)) R *= 2;
         while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
-        if (g_ovr.m_block > 0 && combo_ok(g_ovr.m_block, mt)) R = g_ovr.m_block;
+        if (ov.m_block > 0 && combo_ok(ov.m_block, mt)) R = ov.m_block;
         // SW = 2 slabs per wave (4-bit, no lane sharing, fp16 up to MT = 4 / bf16 up to MT = 2: the bf16 path
         // keeps a second accumulator set): every activation fragment then serves 8 column tiles and the
         // texture-path traffic per MFMA drops by 40 %.  Worth it once halving the slab count still leaves a
@@ -166,26 +324,26 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         if (sw_ok && (long)(units / 32) * mtiles >= (long)num_sms) sw = 2;
         if (sw_ok && bits == 4 && (template_id % 4) == 3) sw = 2;
         if (bits == 4 && (template_id % 4) == 2) sw = 1;
-        if (sw_ok && g_ovr.prescale == 2) sw = 2;
-        if (g_ovr.prescale == 1) sw = 1;
+        if (sw_ok && ov.slabs == 2) sw = 2;
+        if (ov.slabs == 1) sw = 1;
         const int slabs = units * R / 16 / sw;                    // wave-sized column groups
         int nw = (t.threads >= 1024) ? 8 : 4;                     // Threads 1024 / 512 templates
-        if (g_ovr.waves > 0 && g_ovr.waves <= 8) nw = floor_pow2(g_ovr.waves);
+        if (ov.waves > 0 && ov.waves <= 8) nw = floor_pow2(ov.waves);
         while (nw > 1 && tile_geom(bits, R, mt, sw, nw, kMaxLds).depth < 2) nw >>= 1;   // ring of >= 2 slots per wave
         int kw = nw;
         while (kw > 1 && K / kw < 256) kw >>= 1;
         // enough workgroups already: keep more of K per wave (fewer partial tiles to reduce)
         while (kw > 1 && (long)slabs * mtiles / (nw / kw) >= 2L * num_sms * t.sms_multiple && K / kw < 1024) kw >>= 1;
-        if (t.stages == 3 && kw > 1) kw >>= 1;                    // the tuner's handle on the K split (see decode)
+        if (t.stages == 3 && kw > 1) kw >>= 1;                    // the tuner's handle on the K split
         if (t.stages == 4 && kw < nw) kw <<= 1;
         if (t.stages == 5 && kw > 2) kw >>= 2;
-        if (g_ovr.kw > 0 && g_ovr.kw <= nw) kw = floor_pow2(g_ovr.kw);
+        if (ov.kw > 0 && ov.kw <= nw) kw = floor_pow2(ov.kw);
         while (nw % kw) kw >>= 1;
         while (slabs % (nw / kw)) kw <<= 1;
         const long wgs = (long)slabs / (nw / kw) * mtiles;
         int splitk = 1;
         while (wgs * splitk * 2 <= (long)num_sms && K / (splitk * 2 * kw) >= 256) splitk *= 2;
-        if (g_ovr.splitk > 0) splitk = g_ovr.splitk;
+        if (ov.splitk > 0) splitk = ov.splitk;
         int kps = round_up(ceil_div(K, splitk), 32 * kw);
         splitk = ceil_div(K, kps);
         while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
@@ -201,17 +359,23 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
         p->lds_bytes = (size_t)tile_geom(bits, R, mt, sw, nw, kMaxLds).total;
         p->lut_copies = 32;
     }
+    if (rc) return rc;
     p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
     if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
     return FLUTE_OK;
 }
 
+StreamKernel pick_stream_kernel(int bits, int dtype, int tile_p, int mb, int depth) {
+    if (bits == 4) return stream_kernel_b4(dtype, tile_p, mb, depth);
+    if (bits == 3) return stream_kernel_b3(dtype, tile_p, mb, depth);
+    return stream_kernel_b2(dtype, tile_p, mb, depth);
+}
+
 QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles, int sw) {
-    if (family == 0) {
-        const int pre = (g_ovr.prescale > 0) ? g_ovr.prescale : 0;
-        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, pre);
-        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, pre);
-        return decode_kernel_b2(dtype, tile_p, mblk, pre);
+    if (family == kFamilyLegacyDecode) {
+        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, 0);
+        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, 0);
+        return decode_kernel_b2(dtype, tile_p, mblk, 0);
     }
     if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles, sw);
     if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
@@ -221,7 +385,7 @@ QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, i
 // (device, kernel) pairs already granted > 64 KB of dynamic LDS: the attribute is per device, and one
 // process may drive several GPUs (accelerate-style sharded inference)
 struct BigLds { int dev; const void* fn; };
-BigLds g_big_lds[256];
+BigLds g_big_lds[512];
 int g_big_lds_n = 0;
 std::mutex g_big_lds_mu;                       // flute_qgemm may be called from several host threads
 
@@ -236,8 +400,13 @@ int ensure_lds(const void* fn, size_t bytes) {
         (void)hipGetLastError();
         return FLUTE_ERR_LAUNCH;
     }
-    if (g_big_lds_n < 256) g_big_lds[g_big_lds_n++] = BigLds{dev, fn};
+    if (g_big_lds_n < 512) g_big_lds[g_big_lds_n++] = BigLds{dev, fn};
     return 0;
+}
+
+bool hadamard_fusable(const flute_plan& p, int hadamard_size, int K) {
+    return (p.family == 0 || p.family == kFamilyLegacyDecode) && hadamard_size >= 2 && hadamard_size <= 512 &&
+           (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0;
 }
 
 }  // namespace
@@ -262,11 +431,6 @@ const char* flute_strerror(int status) {
     }
 }
 
-void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies,
-                         int prescale) {
-    g_ovr = Overrides{family, m_block, waves, kw, splitk, lut_copies, prescale};
-}
-
 int flute_num_templates(int num_bits) {
     if (num_bits == 4) return 144;
     if (num_bits == 2 || num_bits == 3) return 36;
@@ -279,60 +443,96 @@ int flute_get_template_info(int num_bits, int template_id, flute_template_info* 
     return decode_template(num_bits, template_id, out) ? FLUTE_OK : FLUTE_ERR_TEMPLATE_ID;
 }
 
-int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
-                     int template_id, int num_sms, size_t workspace_bytes, flute_plan* out) {
+int flute_qgemm_plan_ex(int dtype, int num_bits, int group_size, int M, int N, int K, int template_id,
+                        int num_sms, size_t workspace_bytes, const flute_overrides* ovr, flute_plan* out) {
     if (!out) return FLUTE_ERR_NULL;
     return make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
-                     out, nullptr);
+                     ovr_of(ovr), out, nullptr, nullptr);
+}
+
+int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
+                     int template_id, int num_sms, size_t workspace_bytes, flute_plan* out) {
+    return flute_qgemm_plan_ex(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
+                               nullptr, out);
 }
 
 int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, int P,
                 const void* A, const void* Q, void* D, const void* S, const void* QM,
                 const void* QM2, void* workspace, size_t workspace_bytes, int template_id,
                 int num_sms, void* stream) {
-    return flute_qgemm_hadamard(dtype, num_bits, group_size, 0, M, N, K, P, A, Q, D, S, QM, QM2, nullptr,
-                                workspace, workspace_bytes, template_id, num_sms, stream);
+    return flute_qgemm_ex(dtype, num_bits, group_size, 0, M, N, K, P, A, Q, D, S, QM, QM2, nullptr,
+                          workspace, workspace_bytes, template_id, num_sms, nullptr, stream);
 }
 
 int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hadamard_size, int M,
                                int N, int K, int template_id, int num_sms, size_t workspace_bytes) {
     flute_plan p;
-    if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes, &p,
-                  nullptr))
+    if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes, ovr_of(nullptr),
+                  &p, nullptr, nullptr))
         return 0;
-    return (p.family == 0 && hadamard_size >= 2 && hadamard_size <= 512 &&
-            (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0) ? 1 : 0;
+    return hadamard_fusable(p, hadamard_size, K) ? 1 : 0;
 }
 
 int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N,
                          int K, int P, const void* A, const void* Q, void* D, const void* S,
                          const void* QM, const void* QM2, void* x_scratch, void* workspace,
                          size_t workspace_bytes, int template_id, int num_sms, void* stream) {
+    return flute_qgemm_ex(dtype, num_bits, group_size, hadamard_size, M, N, K, P, A, Q, D, S, QM, QM2,
+                          x_scratch, workspace, workspace_bytes, template_id, num_sms, nullptr, stream);
+}
+
+int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N, int K, int P,
+                   const void* A, const void* Q, void* D, const void* S, const void* QM,
+                   const void* QM2, void* x_scratch, void* workspace, size_t workspace_bytes,
+                   int template_id, int num_sms, const flute_overrides* ovr, void* stream) {
     (void)QM;   // single-code table: unused, the kernel reads only the pair table (as the reference)
     if (M == 0) return FLUTE_OK;
-    int had_log = 0;
-    if (hadamard_size > 1) {
-        if (hadamard_size & (hadamard_size - 1)) return FLUTE_ERR_HADAMARD_SIZE;
-        if (flute_qgemm_hadamard_fused(dtype, num_bits, group_size, hadamard_size, M, N, K, template_id,
-                                       num_sms, workspace ? workspace_bytes : 0)) {
-            had_log = ilog2(hadamard_size);              // rotated inside the decode kernel's staging
-        } else {
-            // two launches (qgemm.cpp:201-244): rotate into the caller's scratch, then the plain product
-            if (!A || !x_scratch) return FLUTE_ERR_NULL;
-            const int rc = hadamard_dispatch(dtype, A, x_scratch, (size_t)M * K, (uint32_t)hadamard_size,
-                                             reinterpret_cast<hipStream_t>(stream));
-            if (rc) return rc;
-            A = x_scratch;
-        }
-    }
+    if (hadamard_size > 1 && (hadamard_size & (hadamard_size - 1))) return FLUTE_ERR_HADAMARD_SIZE;
+    // everything is validated before anything is enqueued
     flute_plan p;
     flute_template_info t;
+    StreamArgs sa;
     if (!workspace) workspace_bytes = 0;
     const int rc = make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms,
-                             workspace_bytes, &p, &t);
+                             workspace_bytes, ovr_of(ovr), &p, &t, &sa);
     if (rc) return rc;
     if (P != num_bits * (N / 16)) return FLUTE_ERR_SHAPE;
     if (!A || !Q || !D || !S || !QM2) return FLUTE_ERR_NULL;
+    if (p.splitk > 1 && (!workspace || p.workspace_needed > workspace_bytes)) return FLUTE_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    int had_log = 0;
+    if (hadamard_size > 1) {
+        if (hadamard_fusable(p, hadamard_size, K)) {
+            had_log = ilog2(hadamard_size);              // rotated inside the decode kernel's staging
+        } else {
+            // two launches (qgemm.cpp:201-244): rotate into the caller's scratch, then the plain product
+            if (!x_scratch) return FLUTE_ERR_NULL;
+            const int hrc = hadamard_dispatch(dtype, A, x_scratch, (size_t)M * K, (uint32_t)hadamard_size, st);
+            if (hrc) return hrc;
+            A = x_scratch;
+        }
+    }
+    const float had_scale = 1.0f / sqrtf((float)(1 << had_log));     // as flute_hadamard: bit-identical results
+
+    if (p.family == 0) {
+        sa.A = A; sa.Q = reinterpret_cast<const uint32_t*>(Q); sa.D = D; sa.S = S;
+        sa.QM2 = reinterpret_cast<const uint32_t*>(QM2);
+        sa.partial = reinterpret_cast<float*>(workspace);
+        sa.had_log = had_log; sa.had_scale = had_scale; sa.m0 = 0;
+        StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        void* kargs[] = {&sa};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs,
+                            p.lds_bytes, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        if (p.splitk > 1)
+            return splitk_reduce_dispatch(dtype, sa.partial, D, (size_t)M * N, p.splitk, st);
+        return FLUTE_OK;
+    }
 
     QGemmArgs a;
     a.A = A; a.Q = reinterpret_cast<const uint32_t*>(Q); a.D = D; a.S = S;
@@ -346,9 +546,9 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
     a.lds_budget = kMaxLds;
     a.lkw = ilog2(p.kw);
     a.had_log = had_log;
-    a.had_scale = 1.0f / sqrtf((float)(1 << had_log));       // as flute_hadamard: bit-identical results
+    a.had_scale = had_scale;
     for (int i = 0; i < 10; ++i) a.geo[i] = 0;
-    if (p.family == 0) {
+    if (p.family == kFamilyLegacyDecode) {
         const DecodeGeom g = decode_geom(num_bits, p.m_block, a.lg, p.waves, p.kw, p.k_per_split, kMaxLds);
         a.geo[0] = g.kc; a.geo[1] = g.nbuf; a.geo[2] = g.gcap; a.geo[3] = ilog2(g.upw);
         a.geo[4] = (int)g.x_off; a.geo[5] = (int)g.s_off; a.geo[6] = (int)g.red_off; a.geo[7] = ilog2(g.kc);
@@ -367,7 +567,6 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
     if (!fn) return FLUTE_ERR_TEMPLATE_ID;
     if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
 
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     void* kargs[] = {&a};
     if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs,
                         p.lds_bytes, st) != hipSuccess) {
@@ -379,7 +578,7 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
     return FLUTE_OK;
 }
 
-int flute_hadamard(int dtype, const void* in, void* out, uint32_t numel, uint32_t had_size,
+int flute_hadamard(int dtype, const void* in, void* out, size_t numel, uint32_t had_size,
                    void* stream) {
     if (!in || !out) return numel == 0 ? FLUTE_OK : FLUTE_ERR_NULL;
     return hadamard_dispatch(dtype, in, out, numel, had_size, reinterpret_cast<hipStream_t>(stream));

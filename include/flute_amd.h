@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FLUTE_AMD_ABI_VERSION 2
+#define FLUTE_AMD_ABI_VERSION 3
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -45,13 +45,18 @@ enum flute_status {
  * data/qgemm_kernel_raw_generated_configs.pth) and the same id -> TileP map, so
  * weights packed by the reference for template id X decode correctly here under
  * the same id.  Meaning of the knobs on gfx950:
- *   sms_multiple  target workgroups per CU used to size the K split
- *   threads       workgroup size of the decode kernel (MFMA kernel uses <= 256)
+ *   sms_multiple  decode: weight-ring depth (1: 4 pieces, 2/4: 2 pieces in flight per wave); MFMA kernel:
+ *                 more, smaller workgroups
+ *   threads       upper bound of the decode kernel's workgroup size (1024 / 512); MFMA kernel: 8 / 4 waves
  *   tile_m        rows per wave of the MFMA kernel (16/32/64)
  *   tile_k        64 (granularity of K)
  *   tile_p        packed-layout parameter (32/64) - fixes the wire format
- *   stages        weight prefetch depth (k-steps / load batches)
- *   lut_copies    LDS replicas of the pair table (QuantMapMode: 1/32/16/8) */
+ *   stages        decode: which of the planner's ranked (waves, K split) shapes to launch (2 = best,
+ *                 3/4/5 = the next ones); MFMA kernel: the neighbouring in-workgroup K splits
+ *   lut_copies    the reference's QuantMapMode slot (1/32/16/8): MFMA kernel, 4-bit: automatic / one /
+ *                 two slabs per wave.  The kernels always replicate the pair table 32x in LDS.
+ * The decode kernel applies the group scale in fp32 to an 8-k partial sum: exact on
+ * one-hot inputs, within 2^-11 relative per term of the reference's round_T(lut * s) otherwise. */
 typedef struct flute_template_info {
     int num_bits, template_id;
     int sms_multiple, threads, tile_m, tile_k, tile_p, stages, lut_copies;
@@ -64,7 +69,7 @@ typedef struct flute_plan {
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
-    int waves;           /* waves per workgroup */
+    int waves;           /* waves per workgroup (decode: any count up to 16, not only powers of two) */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
     int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */
     int k_per_split;
@@ -72,7 +77,23 @@ typedef struct flute_plan {
     unsigned grid, block;
     size_t lds_bytes;
     size_t workspace_needed;
+    int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (2/4) */
+    int visits;          /* decode: unit groups the busiest workgroup streams */
+    int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
+    int reserved;
 } flute_plan;
+
+/* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
+ * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
+ *   family          0 decode kernel, 2 (or any value >= 1) MFMA kernel
+ *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)
+ *   waves, kw       waves per workgroup / in-workgroup K split
+ *   splitk          grid-level K split
+ *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
+ *   ring_depth      decode: pieces in flight per wave (2/4) */
+typedef struct flute_overrides {
+    int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth;
+} flute_overrides;
 
 /* D[M,N] = A[M,K] @ (table2-lookup(Q) * S)   fused LUT-dequant GEMM.
  * Replaces _qgemm_raw<T,TQ,T2,NumBits,GroupSize>  (flute/csrc/qgemm.cpp:15-36,
@@ -103,15 +124,25 @@ int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_s
 int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hadamard_size, int M,
                                int N, int K, int template_id, int num_sms, size_t workspace_bytes);
 
+/* flute_qgemm_hadamard with a per-call plan override (ovr may be NULL): what the offline tuner and the
+ * development sweeps call.  hadamard_size 0 = plain flute_qgemm. */
+int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N, int K, int P,
+                   const void* A, const void* Q, void* D, const void* S, const void* QM,
+                   const void* QM2, void* x_scratch, void* workspace, size_t workspace_bytes,
+                   int template_id, int num_sms, const flute_overrides* ovr, void* stream);
+
 /* The plan flute_qgemm would use (exposed for tests and the offline tuner). */
 int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
                      int template_id, int num_sms, size_t workspace_bytes, flute_plan* out);
+int flute_qgemm_plan_ex(int dtype, int num_bits, int group_size, int M, int N, int K,
+                        int template_id, int num_sms, size_t workspace_bytes,
+                        const flute_overrides* ovr, flute_plan* out);
 
 /* out = in.reshape(-1, had_size) @ (H/sqrt(had_size)), Sylvester order.
  * Replaces run_fht<dtype>(a, out, numel, had_size, stream)
  * (flute/csrc/hadamard_transform_cuda.cu:701-748; wrapper hadamard_transform.cpp:17-56;
  * used by apply_hadamard, qgemm.cpp:201-211).  in == out is allowed. */
-int flute_hadamard(int dtype, const void* in, void* out, uint32_t numel, uint32_t had_size,
+int flute_hadamard(int dtype, const void* in, void* out, size_t numel, uint32_t had_size,
                    void* stream);
 
 /* Q[P,K] -> integer codes W[K,N] uint8 on the device.  Native replacement for
@@ -124,14 +155,6 @@ int flute_unpack(int num_bits, int template_id, int N, int K, const void* Q, voi
  * the generated switch, qgemm_kernel_raw_generated.cu:92-767). */
 int flute_num_templates(int num_bits);
 int flute_get_template_info(int num_bits, int template_id, flute_template_info* out);
-
-/* Tuning overrides for the offline tuner / benchmarks; -1 = automatic.
- * family: 0 decode, 2 (or any value >= 1) MFMA.  prescale: 1 = decode kernel rounds lut*scale per
- * pair (fp16 only; the reference's exact arithmetic), 0/-1 = scale applied per
- * 8-k run in fp32.  For family 2, m_block overrides R, lut_copies (1/2/4) the row tiles per wave
- * and prescale (1/2) the slabs per wave.  Process-global, not thread-safe. */
-void flute_set_overrides(int family, int m_block, int waves, int kw, int splitk, int lut_copies,
-                         int prescale);
 
 /* Calibration only: stream `bytes` from `src` with the decode kernel's access shape and
  * no arithmetic (what the HBM path alone costs for a given byte count). */

@@ -45,8 +45,12 @@ def template_ids_for(fa, bits, tile_p, limit=None):
     return ids if limit is None else ids[:limit]
 
 
-def run_qgemm(e, X, Q, S, table, table2, bits, g, tid):
+def run_qgemm(e, X, Q, S, table, table2, bits, g, tid, ovr=None):
     d = e.dev
+    if ovr is not None:       # per-call launch-plan override (flute_qgemm_ex)
+        from flute_amd import dev
+        return dev.qgemm_planned(X.to(d), torch.as_tensor(Q).to(d), S.to(d), table.to(d), table2.to(d),
+                                 e.ws, bits, g, tid, e.num_sms, dev.Overrides(**ovr)).cpu()
     return e.fa.qgemm(X.to(d), torch.as_tensor(Q).to(d), S.to(d), table.to(d), table2.to(d),
                       e.ws, bits, g, tid, e.num_sms).cpu()
 
@@ -154,45 +158,105 @@ def test_ragged_k_and_odd_shapes(env, bits, tile_p):
 
 
 def test_forced_splitk_and_kw_variants(env):
-    """Every K-split mode of both kernel families gives the same answer."""
+    """Every K-split mode of both kernel families gives the same answer: in-workgroup split (kw), grid split
+    (fp32 slabs + reduce pass), any number of waves per workgroup (the decode kernel is not limited to powers
+    of two), both ring depths, and the round-1 decode kernel kept for A/B runs (family 4)."""
     bits, tile_p, g, dtype = 4, 32, 64, torch.float16
     K, N = 4096, 512
     W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=7)
     What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
     tid = template_ids_for(env.fa, bits, tile_p)[0]
-    lib = env.fa._lib.get()
-    try:
-        for M in (1, 4, 8, 16, 64):
+    for M in (1, 4, 8, 16, 64):
+        X = (torch.randn(M, K) / 100).to(dtype)
+        ref = X.float() @ What
+        for kw in (1, 2, 4, 8):
+            for splitk in (1, 2, 4):
+                for waves, depth in ((-1, -1), (8, 2), (12, 4)) if M <= 4 else ((-1, -1),):
+                    if waves > 0 and waves % kw:
+                        continue
+                    ovr = dict(kw=kw, splitk=splitk, waves=waves, ring_depth=depth)
+                    D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, ovr)
+                    err = rel_err(D, ref)
+                    assert err < FP16_TOL, (M, ovr, err)
+        if M <= 4:
+            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=4))
+            assert rel_err(D, ref) < FP16_TOL, (M, "legacy decode")
+
+
+def test_decode_plan_shapes(env):
+    """The streaming decode kernel under every launch shape the planner can produce: odd wave counts, deep K
+    splits with idle waves (more K parts than 512-k pieces), ragged last unit group, several visits per
+    workgroup (num_sms = 4 forces a persistent loop), 2/3/4-bit, both dtypes, all group sizes; one-hot rows
+    bit-exact."""
+    from flute_amd import dev
+    d = env.dev
+    cases = [
+        # bits, tile_p, g, dtype, K, N
+        (4, 32, 64, torch.float16, 2048, 1024), (4, 64, 128, torch.bfloat16, 1536, 1024),
+        (4, 32, 256, torch.float16, 4096, 256), (4, 32, 32, torch.bfloat16, 1024, 512),
+        (2, 32, 64, torch.float16, 2560, 512), (2, 64, 128, torch.bfloat16, 2048, 1024),
+        (3, 32, 64, torch.bfloat16, 2048, 1024), (3, 32, 128, torch.float16, 3072, 512),
+        (4, 32, 64, torch.float16, 4416, 256),          # G = 69: unaligned scale rows (element-wise staging)
+        (4, 32, 64, torch.float16, 192, 128),           # K < one piece
+    ]
+    shapes = [dict(), dict(waves=1, kw=1), dict(waves=3, kw=1), dict(waves=5, kw=1), dict(waves=6, kw=2),
+              dict(waves=8, kw=8), dict(waves=12, kw=4), dict(waves=14, kw=2), dict(waves=16, kw=16),
+              dict(waves=7, kw=1, ring_depth=2), dict(waves=16, kw=1, ring_depth=4), dict(waves=4, kw=4, splitk=2)]
+    for (bits, tile_p, g, dtype, K, N) in cases:
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 91 + bits)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for M in ((1, 2) if bits == 3 else (1, 2, 3, 4)):
             X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
             ref = X.float() @ What
-            for kw in (1, 2, 4, 8):
-                for splitk in (1, 2, 4):
-                    for copies, pre in ((1, 0), (8, 1), (32, 0)):
-                        lib.flute_set_overrides(-1, -1, -1, kw, splitk, copies, pre)
-                        D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
-                        err = rel_err(D, ref)
-                        assert err < FP16_TOL, (M, kw, splitk, copies, pre, err)
-    finally:
-        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            for shp in shapes:
+                for num_sms in (env.num_sms, 4):
+                    ovr = dev.Overrides(**shp)
+                    out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr).cpu()
+                    err = rel_err(out, ref)
+                    assert err < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, shp, num_sms, err)
+                    out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr).cpu()
+                    assert torch.equal(out1, ref1), (bits, tile_p, g, dtype, K, N, M, shp, num_sms)
+
+
+def test_decode_chunked_activations(env):
+    """K ranges whose activations do not fit in LDS at once are staged in chunks (M = 4, K = 28672: 224 KB)."""
+    from flute_amd import dev
+    d = env.dev
+    for (bits, tile_p, g, dtype, K, N, M) in ((4, 32, 64, torch.float16, 28672, 256, 4),
+                                              (4, 64, 128, torch.bfloat16, 28672, 256, 3),
+                                              (3, 32, 64, torch.bfloat16, 28672, 512, 2),
+                                              (2, 32, 64, torch.float16, 36864, 256, 4)):
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 83)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype)
+        assert plan["family"] == 0 and plan["k_chunks"] > 1, plan
+        X = (torch.randn(M, K) / 100).to(dtype)
+        for shp in (dict(), dict(waves=8, kw=8), dict(waves=6, kw=1)):
+            out = dev.qgemm_planned(X.to(d), Q.to(d), S.to(d), table.to(d), table2.to(d), env.ws, bits, g, tid,
+                                    env.num_sms, dev.Overrides(**shp)).cpu()
+            err = rel_err(out, X.float() @ What)
+            assert err < tol_of(dtype), (bits, g, dtype, K, M, shp, err)
 
 
 def test_mfma_family_for_small_M(env):
     """Forcing the MFMA kernel at M <= 8 must agree with the decode kernel."""
     bits, tile_p, g = 4, 64, 128
-    lib = env.fa._lib.get()
     for dtype in (torch.float16, torch.bfloat16):
         K, N = 1024, 512
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=3)
         What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
         tid = template_ids_for(env.fa, bits, tile_p)[0]
-        try:
-            for M in (1, 7):
-                X = (torch.randn(M, K) / 100).to(dtype)
-                lib.flute_set_overrides(2, -1, -1, -1, -1, -1, -1)
-                D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
-                assert rel_err(D, X.float() @ What) < tol_of(dtype)
-        finally:
-            lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
+        for M in (1, 7):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=2))
+            assert rel_err(D, X.float() @ What) < tol_of(dtype)
 
 
 def test_mfma_scale_block_and_ring_paths(env):
@@ -200,9 +264,8 @@ def test_mfma_scale_block_and_ring_paths(env):
     many blocks per wave (no K split), blocks shorter than the ring is deep (g = 32 with 4 lanes per unit),
     a K range that starts mid-block, scale rows that are not 16-B aligned (plain staged loads), a ragged
     last macro-step (K % 128 != 0 with 4 k-steps per weight piece) and a shallow ring (fewer waves)."""
-    lib = env.fa._lib.get()
     cases = [
-        # bits, tile_p, g, dtype, K, N, M, overrides (family, R, waves, kw, splitk, MT, -)
+        # bits, tile_p, g, dtype, K, N, M, overrides (family, R, waves, kw, splitk, MT, slabs per wave)
         (4, 32, 64, torch.float16, 8192, 512, 64, (2, 1, 8, 1, 1, 4, -1)),      # 16 blocks per wave
         (4, 32, 64, torch.bfloat16, 8192, 512, 48, (2, 1, 8, 1, 1, 4, -1)),
         (4, 32, 32, torch.float16, 2048, 512, 16, (2, 4, 8, 1, 1, 1, -1)),      # block = 2 macro-steps < ring depth
@@ -216,25 +279,22 @@ def test_mfma_scale_block_and_ring_paths(env):
         (4, 64, 64, torch.bfloat16, 2048 + 64, 1024, 40, (2, 1, 8, 2, 1, 2, 2)),
         (4, 32, 128, torch.float16, 4096, 512, 33, (2, 1, 4, 2, 2, 2, 2)),
     ]
-    try:
-        for (bits, tile_p, g, dtype, K, N, M, ovr) in cases:
-            W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 97)
-            What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
-            tid = template_ids_for(env.fa, bits, tile_p)[0]
-            X = (torch.randn(M, K) / 100).to(dtype)
-            lib.flute_set_overrides(*ovr)
-            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
-            err = rel_err(D, X.float() @ What)
-            assert err < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, ovr, err)
-            # one-hot rows: bit-exact (each output element is one rounded product)
-            ks = torch.randint(0, K, (M,))
-            E = torch.zeros(M, K, dtype=dtype)
-            E[torch.arange(M), ks] = 1
-            D1 = run_qgemm(env, E, Q, S, table, table2, bits, g, tid)
-            ref = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks]
-            assert torch.equal(D1.float(), ref.to(dtype).float()), (bits, g, dtype, K, ovr)
-    finally:
-        lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
+    for (bits, tile_p, g, dtype, K, N, M, o) in cases:
+        ovr = dict(family=o[0], m_block=o[1], waves=o[2], kw=o[3], splitk=o[4], m_tiles=o[5], slabs_per_wave=o[6])
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 97)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        X = (torch.randn(M, K) / 100).to(dtype)
+        D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, ovr)
+        err = rel_err(D, X.float() @ What)
+        assert err < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, ovr, err)
+        # one-hot rows: bit-exact (each output element is one rounded product)
+        ks = torch.randint(0, K, (M,))
+        E = torch.zeros(M, K, dtype=dtype)
+        E[torch.arange(M), ks] = 1
+        D1 = run_qgemm(env, E, Q, S, table, table2, bits, g, tid, ovr)
+        ref = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks]
+        assert torch.equal(D1.float(), ref.to(dtype).float()), (bits, g, dtype, K, ovr)
 
 
 # ---------------------------------------------------------------------------

@@ -17,6 +17,7 @@ dev = torch.device("cuda:0")
 num_sms = utils.get_device_num_sms(dev)
 ws = utils.get_workspace_streamk(dev)
 lib = _lib.get()
+from flute_amd import dev as dev_mod  # noqa: E402
 fails, total = [], 0
 # SELFCHECK_FAMILY=2: run every automatic case (also M <= 4) through the MFMA kernel
 FORCE_FAMILY = int(os.environ.get("SELFCHECK_FAMILY", "0"))
@@ -43,11 +44,11 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
         for ovr in ovr_list:
             if FORCE_FAMILY and ovr[0] == -1:
                 ovr = (FORCE_FAMILY,) + tuple(ovr[1:])
-            lib.flute_set_overrides(*ovr)
             total += 1
             tag = f"b{bits} tp{tile_p} g{g} {str(dtype)[6:]} K{K} N{N} M{M} ovr{ovr}"
             try:
-                out = flute_amd.qgemm(X, Q, S, table, table2, ws, bits, g, tid, num_sms)
+                out = dev_mod.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms,
+                                            dev_mod.overrides_from_tuple(ovr))
                 torch.cuda.synchronize()
                 err = ((out.float() - ref).norm() / ref.norm()).item()
                 ok = err < tol
@@ -58,7 +59,6 @@ def case(bits, tile_p, g, dtype, K, N, Ms, ovr_list, seed=0):
             except Exception as ex:  # noqa: BLE001
                 fails.append((tag, str(ex)[:200]))
                 print("EXC ", tag, str(ex)[:200], flush=True)
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
     # one-hot exactness through both families
     ks = torch.randint(0, K, (16,), device=dev)
     X = torch.zeros(16, K, device=dev, dtype=dtype)

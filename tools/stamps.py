@@ -19,13 +19,14 @@ dev = torch.device("cuda:0")
 lib = _lib.get()
 f16 = torch.float16
 FAM = int(os.environ.get("STAMPS_FAMILY", "2"))
-dec_cases = [
-    (1, 4096, 4096, (0, -1, 8, 2, 1, -1, 0)),
-    (1, 4096, 4096, (0, -1, 16, 4, 1, -1, 0)),
-    (1, 4096, 4096, (0, -1, 8, 1, 1, -1, 0)),
-    (1, 11008, 4096, (0, -1, 16, 1, 1, -1, 0)),
-    (1, 28672, 8192, (0, -1, 16, 1, 1, -1, 0)),
-    (4, 4096, 4096, (0, -1, -1, -1, -1, -1, 0)),
+dec_cases = [      # streaming decode kernel: (family 0, rows, waves, kw, splitk, -, -, ring depth)
+    (1, 4096, 4096, (0, -1, 8, 2, 1, -1, -1, 4)),
+    (1, 4096, 4096, (0, -1, 16, 4, 1, -1, -1, 4)),
+    (1, 4096, 4096, (0, -1, 16, 4, 1, -1, -1, 2)),
+    (1, 4096, 4096, (0, -1, 8, 4, 1, -1, -1, 4)),
+    (1, 11008, 4096, (0, -1, 11, 1, 1, -1, -1, 4)),
+    (1, 28672, 8192, (0, -1, 14, 1, 1, -1, -1, 4)),
+    (4, 4096, 4096, (0, -1, -1, -1, -1, -1, -1, -1)),
 ]
 cases = [
     (256, 4096, 4096, (FAM, 1, 8, 8, 1, 4, -1)),
@@ -45,8 +46,9 @@ for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
     COLD = os.environ.get("STAMPS_COLD") == "1"      # rotate over > 256 MiB of weight copies: the stamped launch reads HBM
     lay = bench.Layer(M, N, K, 4, 64, f16, dev, bench.copies_for(N, K, 4) if COLD else 2)
     lay.template_id = 16
-    lib.flute_set_overrides(*ovr)
-    plan = utils.get_plan(M, N, K, 4, 64, 16, lay.num_sms, f16)
+    from flute_amd import dev as dev_mod
+    lay.ovr = dev_mod.overrides_from_tuple(ovr)
+    plan = dev_mod.get_plan(M, N, K, 4, 64, 16, lay.num_sms, f16, lay.ovr)
     nwaves = plan["grid"] * plan["waves"]
     ws64 = lay.ws.view(torch.int64)
     for i in range(len(lay.Q) if COLD else 3):
@@ -57,7 +59,6 @@ for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
     lay.step(0)
     torch.cuda.synchronize()
     st = ws64[: nwaves * 8].reshape(nwaves, 8).cpu().double()
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
     t0 = st[:, 0].min()
     us = (st - t0) / 100.0
     q = lambda x: [round(float(v), 2) for v in (x.min(), x.median(), x.max())]  # noqa: E731
@@ -65,8 +66,10 @@ for (M, N, K, ovr) in (dec_cases if FAM == 0 else cases):
          "start_us[min,med,max]": q(us[:, 0]),
          "prologue_us": q(us[:, 1] - us[:, 0]),
          "loop_cycles": q(st[:, 4]), "dma_wait_cycles": q(st[:, 7]), "pro_issue_lut": q(us[:, 5] - us[:, 0]),
-         "dec_args": q(us[:, 7] - us[:, 0]), "dec_setup": q(us[:, 4] - us[:, 7]), "dec_issue": q(us[:, 5] - us[:, 4]), "dec_lut_commit": q(us[:, 6] - us[:, 5]),
-         "dec_stage_barrier": q(us[:, 1] - us[:, 6]),
+         # streaming decode kernel: start -> every prologue load issued -> table/activation data back ->
+         # table image written -> first unit ready (scales staged, barrier) -> first unit streamed -> end
+         "dec_issue": q(us[:, 4] - us[:, 0]), "dec_first_data": q(us[:, 5] - us[:, 4]), "dec_table_image": q(us[:, 6] - us[:, 5]),
+         "dec_x_scales_barrier": q(us[:, 1] - us[:, 6]), "dec_first_unit": q(us[:, 2] - us[:, 1]), "dec_rest": q(us[:, 3] - us[:, 2]),
          "pro_scales": q(us[:, 6] - us[:, 5]), "pro_barrier": q(us[:, 1] - us[:, 6]),
          "mainloop_us": q(us[:, 2] - us[:, 1]),
          "epilogue_us": q(us[:, 3] - us[:, 2]),

@@ -14,13 +14,16 @@ dev = torch.device("cuda:0")
 lib = _lib.get()
 rows = []
 
+from flute_amd.dev import overrides_from_tuple as ovr7  # noqa: E402
+
 
 def run(M, N, K, bits, g, dtype, tid, ovr, steps=300, hot=False):
     lay = bench.Layer(M, N, K, bits, g, dtype, dev, 1 if hot else bench.copies_for(N, K, bits))
     lay.template_id = tid
-    lib.flute_set_overrides(*ovr)
+    lay.ovr = ovr7(ovr)
     try:
-        plan = utils.get_plan(M, N, K, bits, g, tid, lay.num_sms, dtype)
+        from flute_amd import dev as _dev
+        plan = _dev.get_plan(M, N, K, bits, g, tid, lay.num_sms, dtype, lay.ovr)
         ms, _ = bench.time_graph(lay, steps, 10, torch.cuda.synchronize)
         us = ms / steps * 1e3
         r = {"M": M, "N": N, "K": K, "bits": bits, "g": g, "dtype": str(dtype), "tid": tid,
@@ -28,7 +31,6 @@ def run(M, N, K, bits, g, dtype, tid, ovr, steps=300, hot=False):
              "TFLOPs": round(lay.flops() / us / 1e6, 2), "plan": plan}
     except Exception as ex:  # noqa: BLE001
         r = {"M": M, "N": N, "K": K, "bits": bits, "ovr": ovr, "error": str(ex)[:200]}
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
     rows.append(r)
     print(json.dumps(r), flush=True)
     del lay

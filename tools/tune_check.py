@@ -16,7 +16,7 @@ lib = _lib.get()
 for rep in range(3):
     lay = bench.Layer(32, 4096, 4096, 4, 64, torch.float16, dev, bench.copies_for(4096, 4096, 4))
     lay.template_id = 16
-    lib.flute_set_overrides(2, 2, 8, 4, 1, 1, -1)
+    from flute_amd import dev
+    lay.ovr = dev.Overrides(family=2, m_block=2, waves=8, kw=4, splitk=1, m_tiles=1)
     ms, _ = bench.time_graph(lay, 300, 10, torch.cuda.synchronize)
     print("odd config rep", rep, round(ms / 300 * 1e3, 2), utils.get_plan(32, 4096, 4096, 4, 64, 16, lay.num_sms, torch.float16))
-    lib.flute_set_overrides(-1, -1, -1, -1, -1, -1, -1)
