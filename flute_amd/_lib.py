@@ -26,7 +26,7 @@ class Plan(ctypes.Structure):
         ("splitk", c_int), ("k_per_split", c_int), ("lut_copies", c_int),
         ("grid", ctypes.c_uint), ("block", ctypes.c_uint),
         ("lds_bytes", c_size_t), ("workspace_needed", c_size_t),
-        ("ring_depth", c_int), ("visits", c_int), ("k_chunks", c_int), ("reserved", c_int)]
+        ("ring_depth", c_int), ("visits", c_int), ("k_chunks", c_int), ("one_shot", c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

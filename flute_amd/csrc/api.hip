@@ -106,7 +106,7 @@ bool stream_shape(int bits, int mb, int lg, int units, int krange, int G, bool s
         s.x_off = (size_t)lut;
         s.s_off = s.x_off + (size_t)mb * s.kx * 2;
         s.red_off = s.s_off + (size_t)W * s.s_wave_bytes;
-        s.total = s.red_off + (size_t)2 * W * J * mb * 4;
+        s.total = s.red_off + 64 + (size_t)2 * W * J * mb * 4;     // arrival counters + two partial-sum buffers
         if (s.total <= (size_t)kMaxLds) {
             s.nchunks = nch; s.kc = kc;
             const bool chunk_ok = nch == 1 || kc % (8 * g) == 0;
@@ -199,6 +199,14 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     p->lds_bytes = s.total;
     p->lut_copies = 32;
     p->ring_depth = depth; p->visits = s.visits; p->k_chunks = s.nchunks;
+    {   // one-shot variant: single visit, no K chunks, every wave's pieces fit the prologue's D requests
+        const int one_depth = (bits == 3) ? 2 : 4;
+        const int pk = ceil_div(ceil_div(krange, 512), s.kw);
+        const bool one = s.visits == 1 && s.nchunks == 1 && pk <= one_depth &&
+                         s.W * 64 <= stream_max_threads(bits, mb, one_depth) && ov.depth <= 0;
+        p->one_shot = one ? 1 : 0;
+        if (one) p->ring_depth = one_depth;
+    }
     if (sa) {
         memset(sa, 0, sizeof(*sa));
         sa->M = M; sa->N = N; sa->K = K; sa->G = G; sa->lg = lg;
@@ -365,10 +373,10 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     return FLUTE_OK;
 }
 
-StreamKernel pick_stream_kernel(int bits, int dtype, int tile_p, int mb, int depth) {
-    if (bits == 4) return stream_kernel_b4(dtype, tile_p, mb, depth);
-    if (bits == 3) return stream_kernel_b3(dtype, tile_p, mb, depth);
-    return stream_kernel_b2(dtype, tile_p, mb, depth);
+StreamKernel pick_stream_kernel(int bits, int dtype, int tile_p, int mb, int depth, int one_shot) {
+    if (bits == 4) return stream_kernel_b4(dtype, tile_p, mb, depth, one_shot);
+    if (bits == 3) return stream_kernel_b3(dtype, tile_p, mb, depth, one_shot);
+    return stream_kernel_b2(dtype, tile_p, mb, depth, one_shot);
 }
 
 QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles, int sw) {
@@ -520,7 +528,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         sa.QM2 = reinterpret_cast<const uint32_t*>(QM2);
         sa.partial = reinterpret_cast<float*>(workspace);
         sa.had_log = had_log; sa.had_scale = had_scale; sa.m0 = 0;
-        StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth);
+        StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth, p.one_shot);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&sa};

@@ -11,12 +11,12 @@ typedef void (*QGemmKernel)(const QGemmArgs);
 QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb, int pre);
 QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
-// streaming decode kernel (qgemm_stream.h): mb rows per pass (1/2/4; b=3: 1/2), depth = ring slots (2/4)
+// streaming decode kernel (qgemm_stream.h): mb rows per pass (1/2/4; b=3: 1/2), depth = ring slots (2/4), one_shot = the no-refill variant (b=2/4: depth 4, b=3: depth 2)
 struct StreamArgs;
 typedef void (*StreamKernel)(const StreamArgs);
-StreamKernel stream_kernel_b4(int dtype, int tile_p, int mb, int depth);
-StreamKernel stream_kernel_b3(int dtype, int tile_p, int mb, int depth);
-StreamKernel stream_kernel_b2(int dtype, int tile_p, int mb, int depth);
+StreamKernel stream_kernel_b4(int dtype, int tile_p, int mb, int depth, int one_shot);
+StreamKernel stream_kernel_b3(int dtype, int tile_p, int mb, int depth, int one_shot);
+StreamKernel stream_kernel_b2(int dtype, int tile_p, int mb, int depth, int one_shot);
 // MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw);   // sw: slabs per wave (1, 2)
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);

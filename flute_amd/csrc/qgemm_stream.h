@@ -28,6 +28,7 @@
 // (packbits_utils.hpp:139) on one-hot inputs, within 2^-11 relative per term otherwise.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "fwht.h"
@@ -39,7 +40,7 @@ namespace flute_amd {
 __host__ __device__ constexpr int stream_max_threads(int bits, int mb, int depth) {
     if (bits == 4) return (mb == 4 && depth > 2) ? 512 : 1024;
     if (bits == 2) return (mb == 1 || (mb == 2 && depth <= 2)) ? 1024 : 512;
-    return mb == 1 ? 1024 : 512;
+    return 512;        // 3 bits: 16 columns per unit, three planes per ring slot
 }
 __host__ __device__ constexpr int stream_lut_bytes(int bits) { return bits == 3 ? 64 * 128 : 65536; }
 
@@ -69,12 +70,14 @@ struct StreamArgs {
 // ---- hidden loads (hipcc must neither count nor wait for them; see common.h "weight ring") ----
 typedef int srd_t __attribute__((ext_vector_type(4)));
 
+// raw buffer descriptor (stride 0): base must be wave-uniform (kernel arguments, blockIdx and
+// readfirstlane'd wave ids only), otherwise the "s" constraint of the loads below does not compile
 __device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
     const uint64_t p = reinterpret_cast<uint64_t>(base);
     srd_t r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
-    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((p >> 32) & 0xffffu));
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.x = (int)(uint32_t)p;
+    r.y = (int)(uint32_t)((p >> 32) & 0xffffu);
+    r.z = (int)bytes;
     r.w = 0x00020000;
     return r;
 }
@@ -145,9 +148,28 @@ template <> __device__ __forceinline__ float scale_to_float<BF16>(uint32_t raw16
     return __builtin_bit_cast(float, raw16 << 16);
 }
 
-// D = ring depth in pieces (one piece = one 1-KiB wave-wide load per plane = 512 k of one unit)
-template <typename T, int BITS, int TILEP, int MB, int D>
-__global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_kernel(const StreamArgs a) {
+// D = ring depth in pieces (one piece = one 1-KiB wave-wide load per plane = 512 k of one unit).
+// ONE = one-shot variant for the latency-bound launches (every workgroup visits ONE unit group, no K chunks,
+// at most D pieces per wave): all of the wave's weights are requested by the prologue, there is no refill, no
+// load cursor and no scale prefetch - a wave issues an instruction every four cycles at best, so on an 8 MB
+// layer the instruction count of this path IS the launch time once the loads are out.
+template <typename T, int BITS, int TILEP, int MB, int D, bool ONE = false>
+__global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_kernel(const StreamArgs args) {
+    // All kernel arguments are fetched in ONE batch of scalar loads and made opaque: hipcc otherwise treats
+    // every field as rematerialisable and re-reads single dwords from the kernarg segment (s_load + wait, ~100
+    // cycles each, a dozen times in the prologue) instead of keeping or lane-spilling them.
+    StreamArgs a = args;
+    {
+#define FLUTE_OPAQUE(x) asm volatile("" : "+s"(x))
+        FLUTE_OPAQUE(a.A); FLUTE_OPAQUE(a.Q); FLUTE_OPAQUE(a.D); FLUTE_OPAQUE(a.S); FLUTE_OPAQUE(a.QM2);
+        FLUTE_OPAQUE(a.partial); FLUTE_OPAQUE(a.M); FLUTE_OPAQUE(a.N); FLUTE_OPAQUE(a.K); FLUTE_OPAQUE(a.G);
+        FLUTE_OPAQUE(a.lg); FLUTE_OPAQUE(a.units); FLUTE_OPAQUE(a.upw); FLUTE_OPAQUE(a.kw);
+        FLUTE_OPAQUE(a.lkw); FLUTE_OPAQUE(a.nwg); FLUTE_OPAQUE(a.vis_q); FLUTE_OPAQUE(a.vis_r); FLUTE_OPAQUE(a.splitk);
+        FLUTE_OPAQUE(a.k_per_split); FLUTE_OPAQUE(a.kc); FLUTE_OPAQUE(a.nchunks); FLUTE_OPAQUE(a.kx); FLUTE_OPAQUE(a.x_off);
+        FLUTE_OPAQUE(a.s_off); FLUTE_OPAQUE(a.red_off); FLUTE_OPAQUE(a.s_wave_bytes); FLUTE_OPAQUE(a.s_fast);
+        FLUTE_OPAQUE(a.had_log); FLUTE_OPAQUE(a.had_scale); FLUTE_OPAQUE(a.m0);
+#undef FLUTE_OPAQUE
+    }
     using L = Layout<BITS>;
     using NT = Num<T>;
     constexpr int J = L::J;
@@ -174,6 +196,7 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
     const int kpart = wave & (kw - 1);
     const int lg = a.lg;
     const int KX = a.kx;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
 
     int split = 0, wg = blockIdx.x;
     if (a.splitk > 1) { split = blockIdx.x % a.splitk; wg = blockIdx.x / a.splitk; }
@@ -182,147 +205,146 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
     const int nchunks = a.nchunks;
     const int nvis = a.vis_q + (wg < a.vis_r ? 1 : 0);
     const int nseg = nvis * nchunks;
-
-    const uint16_t* A = reinterpret_cast<const uint16_t*>(a.A);
     const uint32_t row_bytes = (uint32_t)a.K * 2u;                 // one Q32 row: K/2 words
 
-    // ---- segment geometry (all wave-uniform): segment = (visit v, chunk c) ----
-    struct Seg { int np, k0, unit, p0; };
-    auto seg_of = [&](int v, int c) -> Seg {
-        Seg s;
-        s.unit = (wg + v * a.nwg) * a.upw + ul;
+    // ---- geometry.  A segment = (visit v, K chunk c) of this wave: np 512-k pieces of unit
+    // (wg + v * nwg) * upw + ul starting at k0.  The K side depends on the chunk only: for the usual
+    // unchunked launch it is computed once. ----
+    struct Geo { int np, k0, p0; };
+    auto chunk_geo = [&](int c) -> Geo {
+        Geo g;
         const int ck0 = kbeg + c * a.kc;
         const int clen = min(a.kc, kend - ck0);
         const int pc = (clen + 511) >> 9;                          // pieces in the chunk
         const int pk = (pc + kw - 1) >> lkw;                       // pieces per wave of the K split
-        s.p0 = kpart * pk;
-        s.np = max(0, min(pk, pc - s.p0));
-        if (s.unit >= a.units) s.np = 0;
-        s.k0 = ck0 + s.p0 * 512;
-        return s;
+        g.p0 = kpart * pk;
+        g.np = max(0, min(pk, pc - g.p0));
+        g.k0 = ck0 + g.p0 * 512;
+        return g;
     };
+    const Geo geo0 = chunk_geo(0);
+    auto unit_of = [&](int v) { return (wg + v * a.nwg) * a.upw + ul; };
+    auto slots_of = [&](int np) { return max(D, (np + D - 1) / D * D); };   // every segment: >= D ring slots
 
-    // ---- prologue: everything the first pieces need travels together, staging data first (loads
-    // return in order): table words, activations of chunk 0, this wave's first scale block, then the ring ----
+    // ---- prologue loads, staging data first (loads return in order): table words, activations of chunk 0,
+    // this wave's first scale block, then the ring ----
     constexpr int ENT = (BITS == 3) ? 64 : 256;
     constexpr int EPB = (BITS == 2) ? 256 : 128;                   // bytes written per table entry (32 copies)
     constexpr int ESTRIDE = (BITS == 3) ? 128 : 256;               // entry stride (b=4: upper half of the stride unused)
-    constexpr int LPIECES = ENT * (EPB / 16);                      // 16-B pieces of the table image
-    constexpr int LUT_R = (BITS == 2) ? 4 : (BITS == 4 ? 2 : 1);   // pieces per thread held in registers (1024 threads)
+    constexpr int EPIECES = EPB / 16;                              // 16-B pieces per entry
+    // thread t owns entry t % ENT and writes pieces t / ENT, t / ENT + P, ... of it (P = threads / ENT,
+    // planned >= 1): ONE table word per thread (two for the 2-bit byte table), whatever the workgroup size
     const srd_t lut_srd = make_srd(a.QM2, (uint32_t)(4 << (2 * BITS)));
-    uint32_t lut_v0[LUT_R], lut_v1[LUT_R];
-#pragma unroll
-    for (int r = 0; r < LUT_R; ++r) {
-        const int e = min(tid + r * nthr, LPIECES - 1) / (EPB / 16);
-        lut_v0[r] = buf_load4((uint32_t)((BITS == 2) ? (e & 15) : e) * 4u, lut_srd);
-        lut_v1[r] = 0;
-        if constexpr (BITS == 2) lut_v1[r] = buf_load4((uint32_t)(e >> 4) * 4u, lut_srd);
-    }
+    const int lut_e = tid & (ENT - 1);
+    uint32_t lut_v0 = buf_load4((uint32_t)((BITS == 2) ? (lut_e & 15) : lut_e) * 4u, lut_srd);
+    uint32_t lut_v1 = 0;
+    if constexpr (BITS == 2) lut_v1 = buf_load4((uint32_t)(lut_e >> 4) * 4u, lut_srd);
 
-    // activations: XP 16-B pieces per thread in registers, the rest by plain loads at commit time
-    constexpr int XP = (MB == 4) ? 4 : 2;
-    const int xpieces = MB * (KX >> 3);
-    ring16_t xv[XP];
-    auto x_src = [&](int pidx, int c, bool& inside) -> const uint16_t* {
-        const int m = (MB == 1) ? 0 : pidx / (KX >> 3);
-        const int kk = (pidx - m * (KX >> 3)) * 8;
-        const int k = kbeg + c * a.kc + kk;
-        inside = (k < kend) && (kk < a.kc);
-        return A + (size_t)min(a.m0 + m, a.M - 1) * a.K + min(k, a.K - 8);
+    // activations: row m of the chunk is staged by all threads, XPR 16-B pieces per thread and row in
+    // registers (the rest by plain loads at commit time).  One descriptor over the whole of A: reads past the
+    // end of A return 0; k >= K inside a row is zeroed at commit.
+    constexpr int XPR = (MB == 4) ? 1 : 2;
+    const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
+    const int xrow_pieces = KX >> 3;
+    ring16_t xv[MB][XPR];
+    auto x_voff = [&](int m, int pidx, int c) -> uint32_t {
+        const int k = kbeg + c * a.kc + pidx * 8;
+        return (pidx < xrow_pieces && k < a.K) ? (uint32_t)(((size_t)min(a.m0 + m, a.M - 1) * a.K + k) * 2) : 0x80000000u;
     };
 #pragma unroll
-    for (int r = 0; r < XP; ++r) {
-        bool inside;
-        const uint16_t* src = x_src(min(r * nthr + tid, xpieces - 1), 0, inside);
-        xv[r] = ring_load16(src);
-    }
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) xv[m][r] = buf_load16(x_voff(m, r * nthr + tid, 0), x_srd, 0);
 
-    // this wave's scale block of a segment: image [granule c][column j][8 groups] T, granule = 16 B.
-    // Fast path: one 16-B load per granule (SPR registers), element loads otherwise.
-    constexpr int SPR = (BITS == 3) ? 4 : 2;                       // granule registers per lane
+    // this wave's scale block of a segment: LDS image [granule c][column j][8 groups] T, granule = 16 B.
+    // Lane q = lane + 64 r fetches granule (j = q >> lgn, c = q & (2^lgn - 1)), 2^lgn >= granules per column.
+    // Fast path: one 16-B load per granule (SPR registers per lane); rows of S that are not 16-B aligned, the
+    // ragged last granule of a row and very long K ranges are staged element-wise at commit time.
+    constexpr int SPR = (BITS == 3) ? 4 : 2;
     const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
     const uint32_t sbase = (uint32_t)a.s_off + (uint32_t)wave * (uint32_t)a.s_wave_bytes;
     ring16_t sv[SPR];
-    struct SStage { int g0, ng, ngran, lgn, unit; };
-    SStage sst = {0, 0, 0, 0, 0};
-    // granule q of a lane = (column j = q >> lgn, chunk c = q & (2^lgn - 1)), 2^lgn >= granules per column
-    auto s_issue = [&](const Seg& s) {                             // unconditional loads (count stays uniform)
-        sst.unit = s.unit;
-        sst.g0 = s.k0 >> lg;
-        sst.ng = (s.np > 0) ? ((min(s.k0 + s.np * 512, kend) - 1) >> lg) - sst.g0 + 1 : 0;
-        sst.ngran = (sst.ng + 7) >> 3;
-        sst.lgn = (sst.ngran > 1) ? 32 - __builtin_clz((unsigned)(sst.ngran - 1)) : 0;
-        const int col0 = unit_col0<BITS, TILEP>(min(s.unit, a.units - 1));
+    struct SGeo { int g0, ng, ngran, lgn; };
+    auto sgeo_of = [&](const Geo& g) -> SGeo {
+        SGeo s;
+        s.g0 = g.k0 >> lg;
+        s.ng = (g.np > 0) ? ((min(g.k0 + g.np * 512, kend) - 1) >> lg) - s.g0 + 1 : 0;
+        s.ngran = (s.ng + 7) >> 3;
+        s.lgn = (s.ngran > 1) ? 32 - __builtin_clz((unsigned)(s.ngran - 1)) : 0;
+        return s;
+    };
+    SGeo sg = sgeo_of(geo0);
+    // per-lane role: relative source offset (bytes, or out of range) and LDS image offset of granule r
+    uint32_t s_rel[SPR], s_img[SPR];
+    auto s_roles = [&]() {
 #pragma unroll
         for (int r = 0; r < SPR; ++r) {
             const int q = lane + 64 * r;
-            const int j = q >> sst.lgn;
-            const int c = q & ((1 << sst.lgn) - 1);
-            const bool ok = a.s_fast && j < J && c < sst.ngran && sst.g0 + c * 8 + 8 <= a.G;
-            const uint32_t off = ok ? (uint32_t)(((size_t)(col0 + j * TILEP) * a.G + sst.g0 + c * 8) * 2) : 0x80000000u;
-            sv[r] = buf_load16(off, s_srd, 0);
+            const int j = q >> sg.lgn;
+            const int c = q & ((1 << sg.lgn) - 1);
+            const bool mine = j < J && c < sg.ngran;
+            const bool fast = mine && a.s_fast && sg.g0 + c * 8 + 8 <= a.G;
+            s_rel[r] = fast ? (uint32_t)(j * TILEP * a.G + c * 8) * 2u : 0x80000000u;
+            s_img[r] = mine ? (uint32_t)(c * J + j) * 16u : 0xffffffffu;
         }
     };
-    auto s_commit = [&]() {
-        const uint16_t* S = reinterpret_cast<const uint16_t*>(a.S);
-        const int col0 = unit_col0<BITS, TILEP>(min(sst.unit, a.units - 1));
-        auto slow_granule = [&](int j, int c) -> uint4 {           // ragged / unaligned granule: element loads, zero fill
-            uint16_t h[8];
-            const uint16_t* sp = S + (size_t)(col0 + j * TILEP) * a.G + sst.g0 + c * 8;
+    auto s_issue = [&](int unit) {                                 // unconditional loads (the count stays uniform)
+        const int col0 = unit_col0<BITS, TILEP>(min(unit, a.units - 1));
+        const uint32_t ubase = (unit < a.units) ? (uint32_t)(col0 * a.G + sg.g0) * 2u : 0x80000000u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) h[e] = (sst.g0 + c * 8 + e < a.G && c * 8 + e < sst.ng) ? sp[e] : (uint16_t)0;
+        for (int r = 0; r < SPR; ++r) sv[r] = buf_load16(ubase + s_rel[r], s_srd, 0);   // either part out of range: 0
+    };
+    auto s_commit = [&](int unit) {
+        const uint16_t* S = reinterpret_cast<const uint16_t*>(a.S);
+        const int col0 = unit_col0<BITS, TILEP>(min(unit, a.units - 1));
+        auto slow_granule = [&](int j, int c) -> uint4 {           // element loads, zero fill
+            uint16_t h[8];
+            const uint16_t* sp = S + (size_t)(col0 + j * TILEP) * a.G + sg.g0 + c * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (sg.g0 + c * 8 + e < a.G && c * 8 + e < sg.ng) ? sp[e] : (uint16_t)0;
             return make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16),
                               h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
         };
 #pragma unroll
         for (int r = 0; r < SPR; ++r) {
-            const int q = lane + 64 * r;
-            const int j = q >> sst.lgn;
-            const int c = q & ((1 << sst.lgn) - 1);
-            if (j < J && c < sst.ngran) {
-                const bool ok = a.s_fast && sst.g0 + c * 8 + 8 <= a.G;
+            if (s_img[r] != 0xffffffffu) {
                 uint4 v = make_uint4(sv[r].x, sv[r].y, sv[r].z, sv[r].w);
-                if (!ok) v = slow_granule(j, c);
-                *reinterpret_cast<uint4*>(smem + sbase + (uint32_t)(c * J + j) * 16u) = v;
+                if (s_rel[r] == 0x80000000u) {                     // not a 16-B granule: element-wise
+                    const int q = lane + 64 * r;
+                    v = slow_granule(q >> sg.lgn, q & ((1 << sg.lgn) - 1));
+                }
+                *reinterpret_cast<uint4*>(smem + sbase + s_img[r]) = v;
             }
         }
-        // columns the SPR x 64 lanes did not reach (long K ranges with small groups): plain passes
-        for (int q = lane + 64 * SPR; (q >> sst.lgn) < J; q += 64) {
-            const int j = q >> sst.lgn;
-            const int c = q & ((1 << sst.lgn) - 1);
-            if (c < sst.ngran) *reinterpret_cast<uint4*>(smem + sbase + (uint32_t)(c * J + j) * 16u) = slow_granule(j, c);
+        for (int q = lane + 64 * SPR; (q >> sg.lgn) < J; q += 64) {    // columns the SPR x 64 lanes did not reach
+            const int j = q >> sg.lgn;
+            const int c = q & ((1 << sg.lgn) - 1);
+            if (c < sg.ngran) *reinterpret_cast<uint4*>(smem + sbase + (uint32_t)(c * J + j) * 16u) = slow_granule(j, c);
         }
     };
 
     // ---- load cursor: runs D slots ahead of the compute cursor, across segment boundaries.  The slot
-    // stream is the concatenation of the wave's segments, each padded to a multiple of D slots (the ring
-    // slot of a piece is then a compile-time constant); padding and exhausted slots are out-of-range loads
-    // (return 0, fetch nothing).  EVERY ring / scale load is unconditional straight-line code: hipcc must
-    // never see an in-flight destination register at a control-flow merge. ----
-    int lv = 0, lc = 0, ls = 0, lp = 0, lnpad = 0;                 // visit, chunk, segment ordinal, slot, padded slots
-    Seg lseg = {0, 0, 0, 0};
+    // stream is the concatenation of the wave's segments, each padded to a whole number (>= 1) of groups of
+    // D slots (the ring slot of a piece is then a compile-time constant and at least D ring loads separate
+    // a scale prefetch from its use); padding and exhausted slots are out-of-range loads (return 0, fetch
+    // nothing).  EVERY ring / scale load is unconditional straight-line code and every counted wait is ONE
+    // statement: hipcc must never see an in-flight destination register at a control-flow merge
+    // (tools/audit_asm_loads.py checks the compiled code for register copies between a load and its wait). ----
+    int lv = 0, lc = 0, ls = 0, lp = 0, lnp = 0, lnpad = D;        // visit, chunk, segment ordinal, slot, pieces, slots
     srd_t lsrd[NP];
     uint32_t lsoff = 0;
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto l_enter = [&]() {                                         // position the cursor on the next non-empty segment
-        while (ls < nseg) {
-            lseg = seg_of(lv, lc);
-            if (lseg.np > 0) break;
-            ++ls; if (++lc == nchunks) { lc = 0; ++lv; }
-        }
-        if (ls < nseg) {
+    auto l_enter = [&]() {
+        const Geo g = (nchunks == 1) ? geo0 : chunk_geo(lc);
+        const int unit = unit_of(lv);
+        const bool live = ls < nseg && unit < a.units;
+        lnp = live ? g.np : 0;
+        lnpad = slots_of(lnp);
+        lsoff = (uint32_t)g.k0 * 2u;
+        const int urow = min(unit, a.units - 1);
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-                lsrd[pl] = make_srd(reinterpret_cast<const char*>(a.Q) +
-                                    (size_t)unit_row<BITS, TILEP>(lseg.unit, pl, a.N) * row_bytes, row_bytes);
-            lsoff = (uint32_t)lseg.k0 * 2u;
-            lnpad = (lseg.np + D - 1) / D * D;
-        } else {
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) lsrd[pl] = make_srd(a.Q, 0);   // exhausted: zero-length descriptor
-            lsoff = 0;
-            lnpad = 0x7fffffff;
-        }
+        for (int pl = 0; pl < NP; ++pl)
+            lsrd[pl] = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit_row<BITS, TILEP>(urow, pl, a.N) * row_bytes,
+                                live ? row_bytes : 0u);            // idle / exhausted: zero-length descriptor
         lp = 0;
     };
     ring16_t q[D][NP];
@@ -330,84 +352,100 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
         // the position travels in the VECTOR offset: only voffset takes part in the descriptor's range check
         // (the scalar offset is excluded from it), and the range check is what turns padding slots and reads
         // past the end of a ragged row into zeros
-        const uint32_t vo = lane16 + ((lp < lseg.np) ? lsoff : 0x80000000u);
+        const uint32_t vo = lane16 + ((lp < lnp) ? lsoff : 0x80000000u);
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) q[i][pl] = buf_load16(vo, lsrd[pl], 0);
         lsoff += 1024u;
         ++lp;
     };
-    // segments are padded to whole groups of D slots, so the cursor can only leave a segment after slot D-1
-    auto l_advance = [&]() {
+    auto l_advance = [&]() {                                       // segments end on group boundaries only
         if (lp == lnpad) {
             ++ls; if (++lc == nchunks) { lc = 0; ++lv; }
             l_enter();
         }
     };
 
-    // first segment's scales, then the ring
-    s_issue((nseg > 0) ? seg_of(0, 0) : Seg{0, 0, a.units, 0});
+    __builtin_amdgcn_sched_barrier(0);                             // table / activation loads are out: now the weights
     l_enter();
 #pragma unroll
     for (int i = 0; i < D; ++i) ring_issue(i);
-    l_advance();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!ONE) l_advance();
+    s_roles();
+    s_issue(unit_of(0));
     FLUTE_SSTAMP(4);
     {
         // loads issued behind the table / activation loads: the scale block and the ring.  The scale block is
         // HBM-cold like the weights; the table and the activations are L2-hot and are written to LDS while it
         // is still in flight (it is waited for at the first segment start below)
-        constexpr int NY = D * NP + SPR;
+        constexpr int NY = D * NP + SPR;                          // younger loads: the ring, then the scale block
+        vm_wait_regs<NY>(lut_v0);
+        vm_wait_regs<NY>(lut_v1);
 #pragma unroll
-        for (int r = 0; r < LUT_R; ++r) { vm_wait_regs<NY>(lut_v0[r]); vm_wait_regs<NY>(lut_v1[r]); }
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int r = 0; r < XP; ++r) vm_wait_regs<NY>(xv[r]);
+            for (int r = 0; r < XPR; ++r) vm_wait_regs<NY>(xv[m][r]);
     }
     FLUTE_SSTAMP(5);
     // ---- table image ----
-#pragma unroll
-    for (int r = 0; r < LUT_R; ++r) {
-        const int p = tid + r * nthr;
-        if (p < LPIECES) {
-            const int e = p / (EPB / 16);
-            const uint32_t v1 = (BITS == 2) ? lut_v1[r] : lut_v0[r];
-            *reinterpret_cast<uint4*>(smem + (size_t)e * ESTRIDE + (p % (EPB / 16)) * 16) =
-                make_uint4(lut_v0[r], v1, lut_v0[r], v1);
+    {
+        const int P = nthr / ENT;
+        const uint32_t v1 = (BITS == 2) ? lut_v1 : lut_v0;
+        const uint4 img = make_uint4(lut_v0, v1, lut_v0, v1);
+        if (tid < P * ENT) {
+            for (int pc = tid / ENT; pc < EPIECES; pc += P)
+                *reinterpret_cast<uint4*>(smem + (size_t)lut_e * ESTRIDE + pc * 16) = img;
         }
-    }
-    for (int p = tid + LUT_R * nthr; p < LPIECES; p += nthr) {     // workgroups smaller than 1024 threads
-        const int e = p / (EPB / 16);
-        uint32_t v0, v1;
-        if constexpr (BITS == 2) { v0 = a.QM2[e & 15]; v1 = a.QM2[e >> 4]; }
-        else { v0 = a.QM2[e]; v1 = v0; }
-        *reinterpret_cast<uint4*>(smem + (size_t)e * ESTRIDE + (p % (EPB / 16)) * 16) = make_uint4(v0, v1, v0, v1);
-    }
-    // ---- activations of a chunk -> LDS [MB][KX], zero beyond the K range; fused pre-rotation: the 64
-    // pieces of a wave are 512 consecutive k of one row = whole Hadamard blocks (K % had == 0, had <= 512) ----
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + a.x_off);
-    auto x_commit = [&](int c, bool from_regs) {
-#pragma unroll
-        for (int r = 0; r < XP; ++r) {
-            const int pidx = r * nthr + tid;
-            if (pidx < xpieces) {
-                bool inside;
-                const uint16_t* src = x_src(pidx, c, inside);
-                uint32_t w[4];
-                if (from_regs) { w[0] = xv[r].x; w[1] = xv[r].y; w[2] = xv[r].z; w[3] = xv[r].w; }
-                else { const uint4 t = *reinterpret_cast<const uint4*>(src); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
-                if (a.had_log > 0) fwht_piece<T>(w, lane, a.had_log, a.had_scale);
-                const uint4 v = inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(xs + (size_t)pidx * 8) = v;
+        if (P == 0) {                                              // fewer threads than table entries (tiny launches)
+            for (int e = tid; e < ENT; e += nthr) {
+                uint32_t w0, w1;
+                if constexpr (BITS == 2) { w0 = a.QM2[e & 15]; w1 = a.QM2[e >> 4]; }
+                else { w0 = a.QM2[e]; w1 = w0; }
+                for (int pc = 0; pc < EPIECES; ++pc)
+                    *reinterpret_cast<uint4*>(smem + (size_t)e * ESTRIDE + pc * 16) = make_uint4(w0, w1, w0, w1);
             }
         }
-        for (int pidx = XP * nthr + tid; pidx < xpieces; pidx += nthr) {
-            bool inside;
-            const uint16_t* src = x_src(pidx, c, inside);
-            const uint4 t = *reinterpret_cast<const uint4*>(src);
-            uint32_t w[4] = {t.x, t.y, t.z, t.w};
-            if (a.had_log > 0) fwht_piece<T>(w, lane, a.had_log, a.had_scale);
-            *reinterpret_cast<uint4*>(xs + (size_t)pidx * 8) = inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+    }
+    // K-split reduction of single-visit launches: arrival counters (one per unit of the workgroup)
+    int* arrive = reinterpret_cast<int*>(smem + a.red_off);
+    if (kw > 1 && tid < a.upw) arrive[tid] = 0;
+    FLUTE_SSTAMP(6);
+
+    // ---- activations of a chunk -> LDS [MB][KX]; fused pre-rotation: the 64 pieces a wave stages are 512
+    // consecutive k of one row = whole Hadamard blocks (K % had == 0, had <= 512) ----
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + a.x_off);
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(a.A);
+    auto x_commit = [&](int c, bool from_regs) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int r = 0; r < XPR; ++r) {
+                const int pidx = r * nthr + tid;
+                if (pidx < xrow_pieces) {                          // wave-uniform: rows are whole 512-k spans
+                    uint32_t w[4];
+                    if (from_regs) { w[0] = xv[m][r].x; w[1] = xv[m][r].y; w[2] = xv[m][r].z; w[3] = xv[m][r].w; }
+                    else {
+                        const int k = min(kbeg + c * a.kc + pidx * 8, a.K - 8);
+                        const uint4 t = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + k);
+                        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+                    }
+                    if (a.had_log > 0) fwht_piece<T>(w, lane, a.had_log, a.had_scale);
+                    const bool inside = kbeg + c * a.kc + pidx * 8 < a.K;
+                    *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
+                        inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+                }
+            }
+            for (int pidx = XPR * nthr + tid; pidx < xrow_pieces; pidx += nthr) {
+                const int k = min(kbeg + c * a.kc + pidx * 8, a.K - 8);
+                const uint4 t = *reinterpret_cast<const uint4*>(A + (size_t)min(a.m0 + m, a.M - 1) * a.K + k);
+                uint32_t w[4] = {t.x, t.y, t.z, t.w};
+                if (a.had_log > 0) fwht_piece<T>(w, lane, a.had_log, a.had_scale);
+                const bool inside = kbeg + c * a.kc + pidx * 8 < a.K;
+                *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
+                    inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
-    FLUTE_SSTAMP(6);
 
     // per-lane constants of the piece loop
     const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
@@ -417,38 +455,51 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
     const int gpp = 512 >> lg;                                     // groups per piece
 
     float acc[J][MB];
-    float* red = reinterpret_cast<float*>(smem + a.red_off);
+    float* red = reinterpret_cast<float*>(smem + a.red_off) + 16;  // behind the arrival counters
     const int W = nthr >> 6;
 
-    // ---- compute cursor: segments in order (empty ones still take part in the barriers) ----
-    int cv = 0, cc = 0;
-    Seg cseg = {0, 0, 0, 0};
-    int prev_slots = D;                                            // ring slots issued since the scale loads in flight
-    auto seg_end = [&]() {
+    // ---- end of a unit: lanes -> wave (DPP) -> [K split: waves -> LDS -> one wave] -> output ----
+    auto store_out = [&](int unit, int j, int m, float v) {
+        const int row = a.m0 + m;
+        if (row < a.M && unit < a.units) {
+            const int n = unit_col0<BITS, TILEP>(unit) + j * TILEP;
+            if (a.splitk == 1) reinterpret_cast<uint16_t*>(a.D)[(size_t)row * a.N + n] = NT::from_float(v);
+            else a.partial[((size_t)split * a.M + row) * a.N + n] = v;
+        }
+    };
+    auto seg_end = [&](int cv, int cc, int unit) {
         if (cc != nchunks - 1) return;
         FLUTE_SSTAMP(2);
-        const int unit = cseg.unit;
-        // lanes -> wave (DPP); K split: waves -> LDS -> first threads
         float tot[J][MB];
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int m = 0; m < MB; ++m) tot[j][m] = wave_sum64(acc[j][m]);
         if (kw == 1) {
-            if (lane == 0 && unit < a.units) {
-                const int n0 = unit_col0<BITS, TILEP>(unit);
+            if (lane == 0) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const int row = a.m0 + m;
-                    if (row < a.M) {
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            if (a.splitk == 1)
-                                reinterpret_cast<uint16_t*>(a.D)[(size_t)row * a.N + n0 + j * TILEP] = NT::from_float(tot[j][m]);
-                            else
-                                a.partial[((size_t)split * a.M + row) * a.N + n0 + j * TILEP] = tot[j][m];
-                        }
-                    }
+                    for (int j = 0; j < J; ++j) store_out(unit, j, m, tot[j][m]);
+            }
+        } else if (nvis == 1) {
+            // single visit (the latency-bound case): no barrier - every wave leaves its partial sums and an
+            // arrival tick in LDS (same wave, in order), the wave that arrives last sums and stores
+            float* rb = red;
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) rb[wave * (J * MB) + j * MB + m] = tot[j][m];
+            }
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == kw - 1) {
+                for (int t = lane; t < J * MB; t += 64) {
+                    float sum = 0.f;
+                    for (int kp = 0; kp < kw; ++kp) sum += rb[(ul * kw + kp) * (J * MB) + t];
+                    store_out(unit, t / MB, t % MB, sum);
                 }
             }
         } else {
@@ -463,145 +514,176 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
             for (int t = tid; t < a.upw * J * MB; t += nthr) {
                 const int ulc = t / (J * MB);
                 const int r = t - ulc * (J * MB);
-                const int j = r / MB;
-                const int m = r - j * MB;
                 float sum = 0.f;
                 for (int kp = 0; kp < kw; ++kp) sum += rb[(ulc * kw + kp) * (J * MB) + r];
-                const int row = a.m0 + m;
-                const int u = (wg + cv * a.nwg) * a.upw + ulc;
-                if (row < a.M && u < a.units) {
-                    const int n = unit_col0<BITS, TILEP>(u) + j * TILEP;
-                    if (a.splitk == 1)
-                        reinterpret_cast<uint16_t*>(a.D)[(size_t)row * a.N + n] = NT::from_float(sum);
-                    else
-                        a.partial[((size_t)split * a.M + row) * a.N + n] = sum;
-                }
+                store_out((wg + cv * a.nwg) * a.upw + ulc, r / MB, r % MB, sum);
             }
         }
     };
 
-
-    for (int cs = 0; cs < nseg; ++cs) {
-        cseg = seg_of(cv, cc);
-        // scales of this segment: prefetched during the previous one (the first: by the prologue)
-        if (prev_slots >= D - 1) {
+    // ---- one piece: 16 k-pairs x J columns per lane.  i = ring slot (compile-time), pch = piece inside the
+    // staged chunk (activations), cp = piece inside the segment (scales) ----
+    auto compute_piece = [&](auto slot_tag, int pch, int cp) {
+        constexpr int i = decltype(slot_tag)::value;
+        const uint32_t xa = x_lane + (uint32_t)pch * 1024u;
+        const int gp = cp * gpp;
+        const uint32_t sa = s_lane + (uint32_t)((gp >> 3) * (J * 16) + (gp & 7) * 2);
+        uint32_t xw[MB][4];
 #pragma unroll
-            for (int r = 0; r < SPR; ++r) vm_wait_regs<(D - 1) * NP>(sv[r]);
+        for (int m = 0; m < MB; ++m) {
+            const uint4 t = lds_ld128(xa + (uint32_t)(m * KX * 2));
+            xw[m][0] = t.x; xw[m][1] = t.y; xw[m][2] = t.z; xw[m][3] = t.w;
+        }
+        uint32_t sc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) sc[j] = lds_ld16(sa + 16u * j);
+        float al[J][MB];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) al[j][m] = 0.f;
+        // The pair lookups are hidden ds_reads (hipcc otherwise funnels them through one or two
+        // registers: address, read, wait, dot, ...): every lookup of a batch is issued back to back,
+        // ONE wait releases them all (cdna_hip_programming.md 5.7 form ii).
+        if constexpr (BITS == 2) {
+#pragma unroll
+            for (int hw = 0; hw < 4; hw += 2) {         // two batches of 8 byte lookups (2 columns each)
+                u32x2_t v[8];
+#pragma unroll
+                for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp)
+                        v[ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[i][0][hw + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
+                lds_lookup_wait8(v);
+#pragma unroll
+                for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            al[2 * jp][m] = NT::dot2(v[ww * 4 + jp].x, xw[m][hw + ww], al[2 * jp][m]);
+                            al[2 * jp + 1][m] = NT::dot2(v[ww * 4 + jp].y, xw[m][hw + ww], al[2 * jp + 1][m]);
+                        }
+            }
+        } else if constexpr (BITS == 4) {
+            uint32_t v[16];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[i][0][ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
+            lds_lookup_wait(v);
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[ww * 4 + j], xw[m][ww], al[j][m]);
         } else {
 #pragma unroll
-            for (int r = 0; r < SPR; ++r) vm_wait_regs<0>(sv[r]);
+            for (int ww = 0; ww < 4; ++ww) {            // one k-pair position: 16 fields in three planes
+                const uint32_t w[3] = {q[i][0][ww], q[i][1][ww], q[i][2][ww]};
+                uint32_t v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = lds_lookup32((field<3>(w, j) << 7) | lane_off);
+                lds_lookup_wait(v);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[j], xw[m][ww], al[j][m]);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float sf = scale_to_float<T>(sc[j]);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[j][m] = __builtin_fmaf(al[j][m], sf, acc[j][m]);
+        }
+                    };
+
+    if constexpr (ONE) {
+        // ---- one-shot: a single segment, every piece already requested ----
+        const int unit = unit_of(0);
+        const int cnp = (unit < a.units) ? geo0.np : 0;
+        x_commit(0, true);
+        __syncthreads();                                           // table / activations visible to every wave
+        if constexpr (NP == 1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[i][0]) : : "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[i][0]), "+v"(q[i][1]), "+v"(q[i][2]) : : "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < SPR; ++r) vm_wait_regs<0>(sv[r]);
+        s_commit(unit);
+        FLUTE_SSTAMP(1);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((I < cnp ? compute_piece(std::integral_constant<int, I>{}, geo0.p0 + I, I) : (void)0), ...);
+        }(std::make_integer_sequence<int, D>{});
+        seg_end(0, 0, unit);
+#ifdef FLUTE_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp[3] = wall_clock64();
+        if (lane == 0 && a.splitk == 1 && a.partial != nullptr) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(a.partial) + ((size_t)blockIdx.x * W + wave) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = stamp[i];
+        }
+#endif
+        return;
+    }
+
+    // ---- compute cursor: segments in order (idle and empty ones still take part in the barriers) ----
+    int cv = 0, cc = 0;
+    for (int cs = 0; cs < nseg; ++cs) {
+        const Geo cg = (nchunks == 1) ? geo0 : chunk_geo(cc);
+        const int unit = unit_of(cv);
+        const int cnp = (unit < a.units) ? cg.np : 0;
         if (cs == 0 || nchunks > 1) {                              // (re)stage the activations of this chunk
             if (cs > 0) __syncthreads();                           // every wave is done with the previous chunk
             x_commit(cc, cs == 0);
+            __syncthreads();                                       // table / activations visible to every wave
         }
-        s_commit();
-        if (cs == 0 || nchunks > 1) __syncthreads();               // table / activations visible to every wave
+        // scales of this segment: prefetched during the previous one with at least D ring slots issued behind
+        // them; the first block is the YOUNGEST load of the prologue
+        if (cs == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#pragma unroll
+        for (int r = 0; r < SPR; ++r) vm_wait_regs<(D - 1) * NP>(sv[r]);
+        s_commit(unit);
         FLUTE_SSTAMP(1);
         {   // prefetch the next segment's scales behind the ring loads already in flight
             int nv = cv, nc = cc + 1;
             if (nc == nchunks) { nc = 0; ++nv; }
-            const Seg ns = (cs + 1 < nseg) ? seg_of(nv, nc) : Seg{0, 0, a.units, 0};
-            s_issue(ns);
+            if (nchunks > 1) { sg = sgeo_of(chunk_geo(nc)); s_roles(); }
+            s_issue((cs + 1 < nseg) ? unit_of(nv) : a.units);
         }
-        prev_slots = 0;
         if (cc == 0) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
                 for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
         }
-        for (int p0 = 0; p0 < cseg.np; p0 += D) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const int cp = p0 + i;
-                // slot i is valid once at most the (D-1) younger slots are outstanding
-                if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[i][0]) : "n"((D - 1) * NP) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(q[i][0]), "+v"(q[i][1]), "+v"(q[i][2]) : "n"((D - 1) * NP) : "memory");
-                if (cp < cseg.np)
-            {
-                const int pch = cseg.p0 + cp;                      // piece inside the staged chunk
-                const uint32_t xa = x_lane + (uint32_t)pch * 1024u;
-                const int gp = cp * gpp;
-                const uint32_t sa = s_lane + (uint32_t)((gp >> 3) * (J * 16) + (gp & 7) * 2);
-                uint32_t xw[MB][4];
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const uint4 t = lds_ld128(xa + (uint32_t)(m * KX * 2));
-                    xw[m][0] = t.x; xw[m][1] = t.y; xw[m][2] = t.z; xw[m][3] = t.w;
-                }
-                uint32_t sc[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) sc[j] = lds_ld16(sa + 16u * j);
-                float al[J][MB];
-#pragma unroll
-                for (int j = 0; j < J; ++j)
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) al[j][m] = 0.f;
-                // The pair lookups are hidden ds_reads (hipcc otherwise funnels them through one or two
-                // registers: address, read, wait, dot, ...): every lookup of a batch is issued back to back,
-                // ONE wait releases them all (cdna_hip_programming.md 5.7 form ii).
-                if constexpr (BITS == 2) {
-#pragma unroll
-                    for (int hw = 0; hw < 4; hw += 2) {             // two batches of 8 byte lookups (2 columns each)
-                        u32x2_t v[8];
-#pragma unroll
-                        for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                            for (int jp = 0; jp < 4; ++jp)
-                                v[ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[i][0][hw + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
-                        lds_lookup_wait8(v);
-#pragma unroll
-                        for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                            for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-                                for (int m = 0; m < MB; ++m) {
-                                    al[2 * jp][m] = NT::dot2(v[ww * 4 + jp].x, xw[m][hw + ww], al[2 * jp][m]);
-                                    al[2 * jp + 1][m] = NT::dot2(v[ww * 4 + jp].y, xw[m][hw + ww], al[2 * jp + 1][m]);
-                                }
-                    }
-                } else if constexpr (BITS == 4) {
-                    uint32_t v[16];
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[i][0][ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
-                    lds_lookup_wait(v);
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[ww * 4 + j], xw[m][ww], al[j][m]);
-                } else {
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {                // one k-pair position: 16 fields in three planes
-                        const uint32_t w[3] = {q[i][0][ww], q[i][1][ww], q[i][2][ww]};
-                        uint32_t v[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) v[j] = lds_lookup32((field<3>(w, j) << 7) | lane_off);
-                        lds_lookup_wait(v);
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-#pragma unroll
-                            for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[j], xw[m][ww], al[j][m]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const float sf = scale_to_float<T>(sc[j]);
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) acc[j][m] = __builtin_fmaf(al[j][m], sf, acc[j][m]);
-                }
-            }
-                ring_issue(i);                                     // refill this slot D slots ahead
-            }
+        const int cpad = slots_of(cnp);
+        auto slot_step = [&](auto slot_tag, int p0) {
+            constexpr int i = decltype(slot_tag)::value;
+            const int cp = p0 + i;
+            // slot i is valid once at most the (D-1) younger slots are outstanding
+            if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[i][0]) : "n"((D - 1) * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(q[i][0]), "+v"(q[i][1]), "+v"(q[i][2]) : "n"((D - 1) * NP) : "memory");
+            if (cp < cnp) compute_piece(slot_tag, cg.p0 + cp, cp);
+            ring_issue(i);                                         // refill this slot D slots ahead
+        };
+        for (int p0 = 0; p0 < cpad; p0 += D) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (slot_step(std::integral_constant<int, I>{}, p0), ...);
+            }(std::make_integer_sequence<int, D>{});
             l_advance();
-            prev_slots += D;
         }
-        seg_end();
+        seg_end(cv, cc, unit);
         if (++cc == nchunks) { cc = 0; ++cv; }
     }
     // the last refills are zero-length reads still landing in q[]: drain before the wave ends

@@ -80,7 +80,7 @@ typedef struct flute_plan {
     int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (2/4) */
     int visits;          /* decode: unit groups the busiest workgroup streams */
     int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
-    int reserved;
+    int one_shot;        /* decode: 1 = one-shot variant (single visit, all weight requests issued by the prologue) */
 } flute_plan;
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
@@ -90,7 +90,8 @@ typedef struct flute_plan {
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split
  *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
- *   ring_depth      decode: pieces in flight per wave (2/4) */
+ *   ring_depth      decode: pieces in flight per wave (2/4); a given depth also selects the ring kernel
+ *                   where the planner would take the one-shot variant */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth;
 } flute_overrides;

@@ -1,0 +1,149 @@
+"""Lint the compiled kernels for the one thing hipcc may legally do to a hidden (inline-asm) load that breaks it:
+touch the destination register between the load and the wait that releases it.
+
+An `asm volatile("buffer_load_dwordx4 %0, ...")` is one opaque instruction to the compiler: it neither counts
+the load nor knows that %0 is not written yet when the statement ends (cdna_hip_programming.md 5.7).  Our
+kernels tie every such register to its counted `s_waitcnt` with a "+v" operand, which orders the USES - but
+the register allocator may still insert a copy (`v_mov`) of the in-flight register ahead of the wait, typically
+at a control-flow merge; the wait then names the copy and the kernel reads stale data on the waves whose
+load had not landed (this happened: round 2, two waits in an if / else).  This script replays each kernel's
+instruction stream in layout order and reports every instruction that reads or writes a VGPR while a hidden
+load into it is still outstanding.
+
+    python tools/audit_asm_loads.py [file.s ...]      # no arguments: compiles the instantiation units to .s
+
+Exit status 1 if anything is flagged.  A linear replay cannot follow branches, so loop-carried state is
+approximate: it is a lint for the straight-line mistakes, not a proof."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "flute_amd", "csrc")
+UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip"]
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*)\s+(\S+),")
+DSLOAD = re.compile(r"^\s*(ds_read_\w+)\s+(\S+),")
+VMCNT = re.compile(r"s_waitcnt\b.*vmcnt\((\d+)\)")
+LGKM = re.compile(r"s_waitcnt\b.*lgkmcnt\((\d+)\)")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def audit(path):
+    findings = []
+    kernel = None
+    in_asm = False
+    vm_fifo = []          # hidden VMEM loads in flight: (line number, set of VGPRs)
+    ds_set = []           # hidden LDS loads in flight
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.split(";")[0].rstrip() if not raw.lstrip().startswith(";;#") else raw.strip()
+        if raw.lstrip().startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.lstrip().startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            kernel = m.group(1)
+            vm_fifo, ds_set = [], []
+            continue
+        if not line.strip() or line.lstrip().startswith(".") or line.rstrip().endswith(":"):
+            if re.match(r"^\.Lfunc_end", line):
+                vm_fifo, ds_set = [], []
+            continue
+        text = line.strip()
+        if text.startswith("s_endpgm"):
+            vm_fifo, ds_set = [], []
+            continue
+        mv = VMCNT.search(text)
+        if mv:
+            n = int(mv.group(1))
+            if n < len(vm_fifo):
+                vm_fifo = vm_fifo[len(vm_fifo) - n:] if n > 0 else []
+        ml = LGKM.search(text)
+        if ml and int(ml.group(1)) == 0:
+            ds_set = []
+        if text.startswith("s_waitcnt"):
+            continue
+        used = regs_of(text)
+        if in_asm:
+            ld = LOAD.match(text)
+            dl = DSLOAD.match(text)
+            if ld:
+                dst = regs_of(ld.group(2))
+                src = regs_of(text[ld.end():])
+                busy = set().union(*[r for _, r in vm_fifo]) if vm_fifo else set()
+                hit = (src | dst) & busy
+                if hit:
+                    findings.append((kernel, ln, text, sorted(hit)))
+                vm_fifo.append((ln, dst))
+                continue
+            if dl:
+                dst = regs_of(dl.group(2))
+                src = regs_of(text[dl.end():])
+                busy = set().union(*[r for _, r in vm_fifo]) if vm_fifo else set()
+                if src & busy:
+                    findings.append((kernel, ln, text, sorted(src & busy)))
+                ds_set.append((ln, dst))
+                continue
+        busy = set()
+        for _, r in vm_fifo:
+            busy |= r
+        for _, r in ds_set:
+            busy |= r
+        hit = used & busy
+        if hit:
+            findings.append((kernel, ln, text, sorted(hit)))
+    return findings
+
+
+def compile_unit(src, outdir):
+    out = os.path.join(outdir, os.path.basename(src)[:-4] + ".s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only",
+                    "-o", out, src], check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def main(argv):
+    files = argv
+    tmp = None
+    if not files:
+        tmp = tempfile.mkdtemp(prefix="flute_audit_")
+        procs = []
+        for u in UNITS:
+            out = os.path.join(tmp, u[:-4] + ".s")
+            procs.append((out, subprocess.Popen(
+                ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only", "-o", out, u],
+                cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+        files = []
+        for out, pr in procs:
+            _, err = pr.communicate()
+            if pr.returncode:
+                print(err.decode()[-2000:])
+                return 2
+            files.append(out)
+    total = 0
+    for f in files:
+        fs = audit(f)
+        total += len(fs)
+        for (k, ln, text, hit) in fs[:40]:
+            print(f"{os.path.basename(f)}:{ln}: {k}: `{text}` touches in-flight v{hit}")
+        print(f"{os.path.basename(f)}: {len(fs)} finding(s)")
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

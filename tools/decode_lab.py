@@ -88,6 +88,11 @@ def check():
                         rows.append(rec)
         del W, S, Q, What
         torch.cuda.empty_cache()
+    import collections
+    by = collections.Counter((r["bits"], r["K"], r["N"], r["M"], json.dumps(r["shape"]), r["num_sms"], r.get("err"), r.get("onehot_exact"))
+                             for r in rows if r.get("kind") == "check" and not r.get("ok"))
+    for k, v in sorted(by.items(), key=str):
+        print("FAILED", k, v, flush=True)
     emit({"kind": "check_summary", "total": len([r for r in rows if r.get("kind") == "check"]), "failed": nfail})
     return nfail
 
