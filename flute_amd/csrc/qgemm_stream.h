@@ -269,7 +269,9 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
         SGeo s;
         s.g0 = g.k0 >> lg;
         s.ng = (g.np > 0) ? ((min(g.k0 + g.np * 512, kend) - 1) >> lg) - s.g0 + 1 : 0;
-        s.ngran = (s.ng + 7) >> 3;
+        // granules are staged for every lane of every piece, also the lanes of a ragged last piece that lie
+        // past the end of K (zero-filled: their activations are zero, but 0 x stale-LDS-NaN would not be)
+        s.ngran = (g.np * (512 >> lg) + 7) >> 3;
         s.lgn = (s.ngran > 1) ? 32 - __builtin_clz((unsigned)(s.ngran - 1)) : 0;
         return s;
     };
