@@ -268,7 +268,7 @@ int plan_legacy_decode(int bits, int lg, int M, int N, int K, int num_sms, const
     return FLUTE_OK;
 }
 
-int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
+int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
               StreamArgs* sa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
@@ -371,6 +371,47 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
     if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
     return FLUTE_OK;
+}
+
+// make_plan is a pure function of its arguments and runs on every call of the operator (ranking the decode
+// shapes costs a few microseconds of host time - as much as the kernel it plans): memoise the last results
+// per host thread.  thread_local, so there is still no shared mutable state.
+struct PlanKey {
+    int dtype, bits, group, M, N, K, template_id, num_sms;
+    size_t workspace_bytes;
+    Ovr ov;
+    bool operator==(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) == 0; }
+};
+struct PlanEntry { PlanKey key; int rc; flute_plan plan; flute_template_info tinfo; StreamArgs sa; bool valid; };
+
+int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
+              size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
+              StreamArgs* sa) {
+    constexpr int kEntries = 32;
+    thread_local PlanEntry cache[kEntries] = {};
+    thread_local int next = 0;
+    PlanKey key;
+    memset(&key, 0, sizeof(key));
+    key.dtype = dtype; key.bits = bits; key.group = group; key.M = M; key.N = N; key.K = K;
+    key.template_id = template_id; key.num_sms = num_sms; key.workspace_bytes = workspace_bytes; key.ov = ov;
+    for (int i = 0; i < kEntries; ++i) {
+        const PlanEntry& e = cache[i];
+        if (e.valid && e.key == key) {
+            if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; }
+            return e.rc;
+        }
+    }
+    PlanEntry& e = cache[next];
+    next = (next + 1) % kEntries;
+    e.valid = false;
+    e.key = key;
+    memset(&e.plan, 0, sizeof(e.plan));
+    memset(&e.sa, 0, sizeof(e.sa));
+    e.rc = make_plan_uncached(dtype, bits, group, M, N, K, template_id, num_sms, workspace_bytes, ov, &e.plan, &e.tinfo,
+                              &e.sa);
+    e.valid = true;
+    if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; }
+    return e.rc;
 }
 
 StreamKernel pick_stream_kernel(int bits, int dtype, int tile_p, int mb, int depth, int one_shot) {

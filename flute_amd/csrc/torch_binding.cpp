@@ -8,8 +8,8 @@
 // call against a 6 us kernel.
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include "../../include/flute_amd.h"
@@ -67,7 +67,8 @@ at::Tensor qgemm_impl(const at::Tensor& input, const at::Tensor& weight, const a
             TORCH_CHECK(K % hadamard_size == 0 || (M * K) % hadamard_size == 0, "shape is invalid for hadamard_size ",
                         hadamard_size);
         }
-        const c10::hip::HIPGuard guard(dev);                                  // qgemm.cpp:101 OptionalCUDAGuard
+        // PyTorch-ROCm keeps DeviceType::CUDA for HIP devices: the "masquerading" guard / stream types
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);                // qgemm.cpp:101 OptionalCUDAGuard
         at::Tensor scratch;
         void* scratch_ptr = nullptr;
         // decode-kernel launches rotate the activations while staging them; every other plan rotates into a
@@ -78,7 +79,7 @@ at::Tensor qgemm_impl(const at::Tensor& input, const at::Tensor& weight, const a
             scratch = at::empty_like(x2d);
             scratch_ptr = scratch.data_ptr();
         }
-        const hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();   // qgemm.cpp:105
+        const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();   // qgemm.cpp:105
         const int rc = flute_qgemm_hadamard(dt, (int)num_bits, (int)group_size, (int)hadamard_size, (int)M, (int)N,
                                             (int)K, (int)weight.size(0), x2d.data_ptr(), weight.data_ptr(),
                                             out.data_ptr(), scales.data_ptr(), table.data_ptr(), table2.data_ptr(),
