@@ -20,6 +20,7 @@
 #include "qgemm_stream.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
+#include "qgemm_block.h"
 
 using namespace flute_amd;
 
@@ -32,6 +33,7 @@ Ovr ovr_of(const flute_overrides* o) {
 }
 
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
 constexpr int kFamilyLegacyDecode = 4;          // round-1 decode kernel, reachable by override only (A/B runs)
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -291,6 +293,20 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     int family = (M <= dec_max) ? 0 : 2;
     if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
     else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
+    // Block-tiled prefill kernel: 4-bit layers whose output has enough 128/256 x 256 blocks to fill the chip
+    // without a K split (the fp32 partial slabs of a split would cost more than the kernel), scale rows in
+    // whole 16-B granules.  cfg 0: 256 x 256 blocks, cfg 1: 128 x 256.
+    int blk_cfg = -1;
+    if (bits == 4 && (K >> lg) % 8 == 0 && units % 64 == 0 && K % 64 == 0 && (family == 2 || ov.family == kFamilyBlock) &&
+        (ov.family < 0 || ov.family == kFamilyBlock)) {
+        const long tiles256 = (long)ceil_div(M, 256) * (units / 64), tiles128 = (long)ceil_div(M, 128) * (units / 64);
+        // measured (tools/block_lab.py): 256-row blocks win from ~0.65 blocks per CU; 128-row blocks only when
+        // they give one block per CU where 256-row blocks would leave half the chip idle
+        if (ov.family == kFamilyBlock) blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
+        else if (M >= 512 && tiles256 * 100 >= (long)num_sms * 65) blk_cfg = 0;
+        else if (M >= 512 && tiles128 * 100 >= (long)num_sms * 90 && tiles128 * 100 <= (long)num_sms * 110) blk_cfg = 1;
+        if (blk_cfg >= 0) family = kFamilyBlock;
+    }
     p->family = family;
 
     int rc = FLUTE_OK;
@@ -298,6 +314,25 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
+    } else if (family == kFamilyBlock) {
+        const int tm = blk_cfg == 0 ? 8 : 4, bm = tm * 32;
+        const int tiles_m = ceil_div(M, bm), tiles_n = units / 64;
+        int splitk = (ov.splitk > 0) ? ov.splitk : 1;
+        const int align_k = std::max(64, 8 << lg);
+        int kps = round_up(ceil_div(K, splitk), align_k);
+        splitk = ceil_div(K, kps);
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+            splitk >>= 1;
+            kps = round_up(ceil_div(K, splitk), align_k);
+            splitk = ceil_div(K, kps);
+        }
+        if (splitk == 1) kps = K;
+        p->m_block = blk_cfg; p->m_tiles = tm; p->slabs_per_wave = 1; p->waves = 8; p->kw = 1;
+        p->splitk = splitk; p->k_per_split = kps;
+        p->grid = (unsigned)((long)tiles_m * tiles_n * splitk);
+        p->block = 512;
+        p->lds_bytes = (size_t)block_lds_bytes(bits, tm, 2, 4);
+        p->lut_copies = 32;
     } else {
         // M > decode range: MFMA kernel (qgemm_tile.h).  MT 16-row tiles per wave (1 for M <= 16),
         // R lanes share a unit: pick the smallest R whose slab x row-tile count fills the chip; the
@@ -580,6 +615,32 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         }
         if (p.splitk > 1)
             return splitk_reduce_dispatch(dtype, sa.partial, D, (size_t)M * N, p.splitk, st);
+        return FLUTE_OK;
+    }
+
+    if (p.family == kFamilyBlock) {
+        BlockArgs b;
+        memset(&b, 0, sizeof(b));
+        b.A = A; b.Q = reinterpret_cast<const uint32_t*>(Q); b.D = D; b.S = S;
+        b.QM2 = reinterpret_cast<const uint32_t*>(QM2);
+        b.partial = reinterpret_cast<float*>(workspace);
+        b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
+        const int bm = p.m_tiles * 32;
+        b.tiles_m = ceil_div(M, bm); b.tiles_n = (N / 4) / 64;
+        b.splitk = p.splitk; b.k_per_split = p.k_per_split;
+        // XCD x (block id % 8) owns a contiguous range of row blocks (their activations then stay in its L2
+        // while the weights stream through), else of column blocks
+        b.order = (b.tiles_m % 8 == 0) ? 1 : ((b.tiles_n % 8 == 0) ? 2 : 0);
+        BlockKernel fn = block_kernel_b4(dtype, t.tile_p, p.m_block);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        void* kargs[] = {&b};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        if (p.splitk > 1) return splitk_reduce_dispatch(dtype, b.partial, D, (size_t)M * N, p.splitk, st);
         return FLUTE_OK;
     }
 

@@ -1,0 +1,13 @@
+// Explicit instantiations of the block-tiled prefill kernel (qgemm_block.h) for num_bits = 4.
+#include "kernels.h"
+#include "qgemm_block.h"
+namespace flute_amd {
+// cfg 0: 256 x 256 block (TM = 8 row tiles per wave, 2 x 4 waves); cfg 1: 128 x 256 (TM = 4)
+BlockKernel block_kernel_b4(int dtype, int tile_p, int cfg) {
+    if (tile_p == 32 && cfg == 0) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 32, 8, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 32, 8, 2, 4>;
+    if (tile_p == 64 && cfg == 0) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 8, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 8, 2, 4>;
+    if (tile_p == 32 && cfg == 1) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 32, 4, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 32, 4, 2, 4>;
+    if (tile_p == 64 && cfg == 1) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 4, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 4, 2, 4>;
+    return nullptr;
+}
+}  // namespace flute_amd

@@ -17,6 +17,10 @@ typedef void (*StreamKernel)(const StreamArgs);
 StreamKernel stream_kernel_b4(int dtype, int tile_p, int mb, int depth, int one_shot);
 StreamKernel stream_kernel_b3(int dtype, int tile_p, int mb, int depth, int one_shot);
 StreamKernel stream_kernel_b2(int dtype, int tile_p, int mb, int depth, int one_shot);
+// block-tiled prefill kernel (qgemm_block.h): cfg 0 = 256 x 256 block, cfg 1 = 128 x 256
+struct BlockArgs;
+typedef void (*BlockKernel)(const BlockArgs);
+BlockKernel block_kernel_b4(int dtype, int tile_p, int cfg);
 // MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw);   // sw: slabs per wave (1, 2)
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);

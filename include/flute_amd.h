@@ -65,7 +65,8 @@ typedef struct flute_template_info {
 /* Launch plan chosen for a problem (host logic only, no GPU needed). */
 typedef struct flute_plan {
     int family;          /* 0 = decode (streaming GEMV, M<=4; 3 bits: M<=2), 2 = MFMA kernel with
-                            LDS-DMA staged operands (every larger M) */
+                            LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
+                            (4-bit, enough 128/256 x 256 output blocks to fill the chip) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
@@ -85,7 +86,8 @@ typedef struct flute_plan {
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
- *   family          0 decode kernel, 2 (or any value >= 1) MFMA kernel
+ *   family          0 decode kernel, 2 (or any other value >= 1) per-wave MFMA kernel, 3 block-tiled
+ *                   prefill kernel (m_tiles 8 / 4 picks its 256 / 128-row block), 4 round-1 decode kernel
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split
