@@ -60,6 +60,13 @@ __device__ __forceinline__ void dma16_buf(uint32_t voff, srd_t srd, uint32_t sof
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
+// releases 8 hidden lookups once at most N younger LDS operations are outstanding
+template <int N> __device__ __forceinline__ void blk_lookup_wait(uint32_t (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(N) : "memory");
+}
+
 template <typename T, int BITS, int TILEP, int TM, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void qgemm_block_kernel(const BlockArgs args) {
     static_assert(BITS == 4 || BITS == 2, "3-bit layers use the per-wave MFMA kernel (qgemm_tile.h)");
@@ -224,31 +231,33 @@ __global__ __launch_bounds__(WM * WN * 64) void qgemm_block_kernel(const BlockAr
                     af[tm] = u32x4_t{v.x, v.y, v.z, v.w};
                 }
                 const u32x4_t qw = w[slot][h];
-                constexpr int JB = (J > 4) ? 4 : J;                // column tiles per lookup batch (16 lookups)
+                // Lookups in batches of two column tiles (8 hidden ds_reads each), all issued up front; batch b is
+                // released by a COUNTED wait (LDS returns in order; the main loop issues no scalar loads), so the
+                // multiplies and MFMAs of batch b run while the later batches are still in flight.
+                constexpr int NB = J / 2;
+                uint32_t v[NB][8];
 #pragma unroll
-                for (int j0 = 0; j0 < J; j0 += JB) {
-                    uint32_t v[16];
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int jj = 0; jj < JB; ++jj)
+                    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int ww = 0; ww < 4; ++ww) {
-                            const uint32_t idx = __builtin_amdgcn_ubfe(qw[ww], (uint32_t)(2 * BITS * (j0 + jj)), (uint32_t)(2 * BITS));
-                            v[jj * 4 + ww] = lds_lookup32((idx << 7) | lane_off);
+                            const uint32_t idx = __builtin_amdgcn_ubfe(qw[ww], (uint32_t)(2 * BITS * (2 * b + jj)), (uint32_t)(2 * BITS));
+                            v[b][jj * 4 + ww] = lds_lookup32((idx << 7) | lane_off);
                         }
-                    if constexpr (JB < 4) {
+                [&]<int... B>(std::integer_sequence<int, B...>) {
+                    ([&] {
+                        blk_lookup_wait<(NB - 1 - B) * 8>(v[B]);
 #pragma unroll
-                        for (int e = JB * 4; e < 16; ++e) v[e] = 0;
-                    }
-                    lds_lookup_wait(v);
+                        for (int jj = 0; jj < 2; ++jj) {
+                            u32x4_t bf;
 #pragma unroll
-                    for (int jj = 0; jj < JB; ++jj) {
-                        u32x4_t bf;
+                            for (int ww = 0; ww < 4; ++ww) bf[ww] = NT::mul_scale(v[B][jj * 4 + ww], sc[2 * B + jj]);
 #pragma unroll
-                        for (int ww = 0; ww < 4; ++ww) bf[ww] = NT::mul_scale(v[jj * 4 + ww], sc[j0 + jj]);
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) acc[tm][j0 + jj] = Mfma<T>::run(bf, af[tm], acc[tm][j0 + jj]);
-                    }
-                }
+                            for (int tm = 0; tm < TM; ++tm) acc[tm][2 * B + jj] = Mfma<T>::run(bf, af[tm], acc[tm][2 * B + jj]);
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, NB>{});
             }
         }
     };

@@ -14,15 +14,22 @@ the layer's extra state `{num_bits, group_size, template_id}`.  Loading is three
    gfx950 tuner picks a plan and the codes are packed again.
 
 What differs from the reference, on purpose:
-* the packed template id comes from the checkpoint's own extra state; the A100 table
-  `qgemm_kernel_raw_tuned_configs.no-M.pth` (`:53-83`) is only a fallback that the
-  caller may point to with `legacy_template_table=`;
-* one distinct (N, K) shape is tuned once per model, not once per layer.
+* the packed template id comes from the checkpoint's own extra state when it has one.  Safetensors
+  checkpoints on the Hub do not: the reference then takes the id from its bundled per-GPU table
+  `qgemm_kernel_raw_tuned_configs.no-M.pth` (`:53-83`).  Only the TileP of that id matters to the native
+  unpacker, and EVERY entry of that table (3 816: A100 / A6000 / RTX 4090, 2-4 bits, g 32-256, fp16 / bf16)
+  is a TileP = 32 template (`flute_amd/data/ref_packed_tilep.json`, generated and asserted by
+  `tools/make_ref_tilep_table.py`): a layer without a template id is unpacked as TileP = 32.  The caller
+  may still point `legacy_template_table=` at a `.pth` table of ids;
+* one distinct (N, K) shape is tuned once per model, not once per layer, and shapes found in the shipped
+  gfx950 table (`flute_amd/data/gfx950_tuned.json`) are not timed at all.
 
 `FluteConfig` / `FluteHfQuantizer` register the method with `transformers`
 (written against the 5.x quantizer API of this image); they are defined only if
 `transformers` imports, the two functions above need torch alone.
 """
+import json
+import os
 import warnings
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -34,6 +41,19 @@ from flute_amd import tune
 from flute_amd.integrations.base import FluteLinear
 
 FLUTE_CONFIG_FILE_NAME = "flute_config.json"        # flute/integrations/base.py:21
+_REF_TILEP_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data",
+                               "ref_packed_tilep.json")
+
+
+def reference_packed_tile_p() -> int:
+    """TileP of every template the reference's bundled tuned table assigns (see the module docstring)."""
+    with open(_REF_TILEP_FILE) as f:
+        return int(json.load(f)["default_tile_p"])
+
+
+def template_id_with_tile_p(num_bits: int, tile_p: int) -> int:
+    """A template id of this library's table with the given packed layout (id -> TileP is the reference's map)."""
+    return min(t for (b, t), c in flute_amd.TEMPLATE_CONFIGS.items() if b == num_bits and c["TileP"] == tile_p)
 
 
 def _skip(name: str, path: str, modules_to_not_convert: List[str]) -> bool:
@@ -83,7 +103,9 @@ def repack_flute_linear(model: torch.nn.Module, num_sms_packed: int, example_bat
     for name, module in model.named_children():
         if isinstance(module, FluteLinear) and getattr(module, "needs_repacking", False):
             if module.template_id is None:
-                raise ValueError(f"{name}: the checkpoint carried no template id and none was supplied")
+                # no extra state (safetensors) and no table of ids: the reference's own table only ever
+                # assigns TileP = 32 templates, and TileP is all the unpacker needs
+                module.template_id = template_id_with_tile_p(module.num_bits, reference_packed_tile_p())
             home = module.weight.device
             device = home if home.type == "cuda" else torch.device("cuda")
             if home.type != "cuda":

@@ -10,6 +10,7 @@ Same API as the reference (`TuneMetaData`, `tune_and_pack`, `check`, `qgemm_v2`,
   * the accepted error is the reference's (FP16 2.0e-3 / BF16 1.1e-2,
     tune.py:13-14) and failures RAISE instead of printing in red.
 """
+import json
 import os
 import warnings
 from typing import Dict, List, NamedTuple, Optional, Tuple
@@ -21,6 +22,8 @@ from . import _lib
 from . import utils
 
 _TEMPLATES: Dict = {}
+_TUNED_TABLE: Optional[Dict] = None
+TUNED_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gfx950_tuned.json")
 FP16_ERROR_THRESHOLD = 2.0e-3
 BF16_ERROR_THRESHOLD = 1.1e-2
 _L3_BYTES = 256 * 1024 * 1024
@@ -64,6 +67,52 @@ def get_template_key(M, N, K, num_bits, group_size, num_sms, dtype, legacy=False
     return ("v1", M if M <= 4 else max(M, 16), N, K, num_bits, group_size, num_sms, dtype)
 
 
+# ---------------------------------------------------------------------------
+# shipped tuning results (the role of flute/data/qgemm_kernel_raw_tuned_configs*.pth + tune_tasks_legacy,
+# flute/tune.py:466-494): `python -m flute_amd.tune` times the reference's SUPPORTED_SHAPES on an MI355X once
+# and writes flute_amd/data/gfx950_tuned.json; `_tune` answers from it without touching the GPU.
+# ---------------------------------------------------------------------------
+
+
+def m_bucket(M: int) -> int:
+    """Batch sizes that share a tuned entry: the decode kernel's row counts 1..4 each, then powers of two."""
+    if M <= 4:
+        return M
+    b = 16
+    while b < M and b < 4096:
+        b *= 2
+    return b
+
+
+def tuned_key(M, N, K, num_bits, group_size, num_sms, dtype, tile_p=None) -> str:
+    return f"{m_bucket(M)}|{N}|{K}|{num_bits}|{group_size}|{num_sms}|{str(dtype).replace('torch.', '')}|{tile_p or 0}"
+
+
+def load_tuned_table(path: Optional[str] = None) -> Dict[str, int]:
+    global _TUNED_TABLE
+    if path is None and _TUNED_TABLE is not None:
+        return _TUNED_TABLE
+    p = path or TUNED_TABLE_PATH
+    table: Dict[str, int] = {}
+    if os.path.exists(p):
+        with open(p) as f:
+            table = {k: int(v) for k, v in json.load(f).get("entries", {}).items()}
+    if path is None:
+        _TUNED_TABLE = table
+    return table
+
+
+def lookup_tuned(M, N, K, num_bits, group_size, num_sms, dtype, tile_p=None) -> Optional[int]:
+    """Template id from the shipped table (None: not tuned offline).  FLUTE_AMD_RETUNE=1 ignores the table."""
+    if os.environ.get("FLUTE_AMD_RETUNE") == "1":
+        return None
+    table = load_tuned_table()
+    tid = table.get(tuned_key(M, N, K, num_bits, group_size, num_sms, dtype, tile_p))
+    if tid is None and tile_p is None:
+        return None
+    return tid
+
+
 def do_bench(fn, args_list: List[Tuple], warmup: int = 5, rep: int = 50) -> float:
     """Milliseconds per call of fn(*args), cycling over args_list.
 
@@ -83,6 +132,8 @@ def do_bench(fn, args_list: List[Tuple], warmup: int = 5, rep: int = 50) -> floa
             for i in range(rep):
                 fn(*args_list[i % n])
     except RuntimeError as ex:
+        # torch.cuda.graph() has already ended (aborted) the capture when the body raised
+        torch.cuda.synchronize()
         if "invalid argument" in str(ex) or str(ex).startswith("Unsupported template_id value"):
             raise
         graph = None
@@ -138,6 +189,10 @@ def _tune(M, N, K, num_bits, group_size, num_sms, dtype, device, num_seeds=1,
     key = get_template_key(M, N, K, num_bits, group_size, num_sms, dtype) + (tile_p,)
     if key in _TEMPLATES:
         return _TEMPLATES[key]
+    shipped = lookup_tuned(M, N, K, num_bits, group_size, num_sms, dtype, tile_p)
+    if shipped is not None and utils.is_template_supported(M, N, K, num_bits, shipped, num_sms, group_size, dtype):
+        _TEMPLATES[key] = shipped
+        return shipped
     cands = candidate_templates(M, N, K, num_bits, group_size, num_sms, dtype)
     if tile_p is not None:
         cands = [t for t in cands if flute_amd.TEMPLATE_CONFIGS[(num_bits, t)]["TileP"] == tile_p]
@@ -157,6 +212,9 @@ def _tune(M, N, K, num_bits, group_size, num_sms, dtype, device, num_seeds=1,
             if "invalid argument" in str(e) or str(e).startswith("Unsupported template_id value"):
                 continue
             raise
+    if not times:
+        raise RuntimeError(f"no template could be launched for M={M} N={N} K={K} num_bits={num_bits} "
+                           f"group_size={group_size} (every candidate raised a launch / template error)")
     best = min(times, key=times.get)
     _TEMPLATES[key] = best
     return best
@@ -185,9 +243,21 @@ def check(weight: torch.Tensor, weight_packed: torch.Tensor, metadata: TuneMetaD
     output = flute_amd.qgemm(inputs, weight_packed, scales, tables, tables2, workspace,
                              metadata.num_bits, metadata.group_size, metadata.template_id,
                              metadata.num_sms)
+    if os.environ.get("FLUTE_AMD_OPCHECK") == "1":      # flute/tune.py:350-360 (off by default: seconds per call)
+        torch.library.opcheck(flute_amd.qgemm, (inputs, weight_packed, scales, tables, tables2, workspace,
+                                                metadata.num_bits, metadata.group_size, metadata.template_id,
+                                                metadata.num_sms))
     if identity:
         if not (output_ == output).all().item():
             raise AssertionError(f"[FLUTE] identity check failed: {metadata}")
+        # M = K runs the MFMA kernels; the streaming decode kernel (M <= 4) applies the group scale in fp32 to an
+        # 8-k partial sum - exact on one-hot rows: check it on the first / last / middle rows of the identity
+        rows = torch.tensor([0, metadata.K // 2, metadata.K - 1, 1][: (2 if metadata.num_bits == 3 else 4)], device=dev)
+        for m in (1, rows.numel()):
+            out_dec = flute_amd.qgemm(inputs[rows[:m]].contiguous(), weight_packed, scales, tables, tables2, workspace,
+                                      metadata.num_bits, metadata.group_size, metadata.template_id, metadata.num_sms)
+            if not torch.equal(out_dec, output_[rows[:m]]):
+                raise AssertionError(f"[FLUTE] decode-kernel one-hot check failed (M={m}): {metadata}")
         return
     error = ((output_ - output).norm() / output.norm()).item()
     error_ = ((output_ - output).norm() / output_.norm()).item()
@@ -259,3 +329,91 @@ def maybe_tune_and_repack(weight: torch.Tensor, scales: torch.Tensor, metadata: 
     if weight_repacked.shape != weight.shape or weight_repacked.dtype != weight.dtype:
         raise ValueError
     return weight_repacked, tune_metadata
+
+
+# ---------------------------------------------------------------------------
+# offline tuner CLI:  python -m flute_amd.tune [--shapes supported|llama3|N,K;N,K...] [--ms 1,16,256] ...
+# ---------------------------------------------------------------------------
+
+# the reference's tests/shapes.py:1-96 (N, K)
+SUPPORTED_SHAPES = [
+    (1024, 4096), (4096, 4096), (4096, 14336), (6144, 4096), (14336, 4096),
+    (1024, 8192), (8192, 8192), (8192, 28672), (10240, 8192), (28672, 8192),
+    (5120, 8192), (8192, 4096), (8192, 14336), (14336, 8192),
+    (2560, 8192), (7168, 8192), (8192, 2048), (8192, 7168),
+    (2048, 16384), (2560, 16384), (5120, 16384), (16384, 2048), (16384, 4096), (16384, 6656), (16384, 16384),
+    (16384, 53248), (16384, 13312), (53248, 16384), (20480, 16384), (26624, 16384), (13312, 16384), (106496, 16384),
+    (28672, 4096), (57344, 8192),
+    (2048, 3584), (3584, 4096), (3584, 14336), (4096, 3584), (14336, 3584), (8192, 3584), (28672, 3584),
+    (2048, 4608), (4096, 4608), (4608, 4096), (4608, 36864), (36864, 4608), (8192, 4608), (73728, 4608),
+    (4608, 2048), (4608, 18432), (4608, 1024), (4608, 9216), (18432, 4608),
+]
+EXTRA_SHAPES = [(11008, 4096), (4096, 11008), (3584, 8192)]       # BASELINE.json configs[1], TP-8 shard of configs[3]
+
+
+def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: float = 1e9, rep: int = 40) -> Dict:
+    """flute/tune.py:466-494 (tune_tasks_legacy): time every task once on this GPU, persist the winners."""
+    import time
+    device = torch.device("cuda")
+    num_sms = utils.get_device_num_sms(device)
+    existing = {}
+    if os.path.exists(out_path):
+        with open(out_path) as f:
+            existing = json.load(f).get("entries", {})
+    entries = dict(existing)
+    t0 = time.time()
+    done = skipped = 0
+    os.environ["FLUTE_AMD_RETUNE"] = "1"
+    for (N, K) in shapes:
+        for bits in bits_list:
+            for g in groups:
+                for dtype in dtypes:
+                    for M in ms:
+                        for tile_p in ((None,) if bits == 3 else (None, 32)):
+                            k = tuned_key(M, N, K, bits, g, num_sms, dtype, tile_p)
+                            if k in entries:
+                                continue
+                            if time.time() - t0 > budget_s:
+                                skipped += 1
+                                continue
+                            try:
+                                tid = _tune(M, N, K, bits, g, num_sms, dtype, device, tile_p=32 if bits == 3 else tile_p, rep=rep)
+                            except RuntimeError:
+                                continue
+                            entries[k] = int(tid)
+                            done += 1
+                    torch.cuda.empty_cache()
+        with open(out_path, "w") as f:
+            json.dump({"device": torch.cuda.get_device_name(device), "num_sms": num_sms,
+                       "key": "M bucket|N|K|num_bits|group_size|num_sms|dtype|TileP constraint (0 = any)",
+                       "entries": dict(sorted(entries.items()))}, f, indent=0)
+    os.environ.pop("FLUTE_AMD_RETUNE", None)
+    return {"tuned": done, "skipped_for_time": skipped, "total_entries": len(entries), "seconds": round(time.time() - t0, 1)}
+
+
+def _main() -> None:
+    import argparse
+    ap = argparse.ArgumentParser(description="offline template tuner for gfx950 (writes the shipped table)")
+    ap.add_argument("--shapes", default="supported", help="supported | extra | 'N,K;N,K;...'")
+    ap.add_argument("--ms", default="1,2,4,16,64,256,1024")
+    ap.add_argument("--bits", default="4,3,2")
+    ap.add_argument("--groups", default="64,128")
+    ap.add_argument("--dtypes", default="float16,bfloat16")
+    ap.add_argument("--out", default=TUNED_TABLE_PATH)
+    ap.add_argument("--budget-s", type=float, default=1e9)
+    ap.add_argument("--rep", type=int, default=40)
+    a = ap.parse_args()
+    if a.shapes == "supported":
+        shapes = EXTRA_SHAPES + SUPPORTED_SHAPES
+    elif a.shapes == "extra":
+        shapes = EXTRA_SHAPES
+    else:
+        shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes.split(";")]
+    dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}
+    r = tune_tasks(shapes, [int(v) for v in a.ms.split(",")], [int(v) for v in a.bits.split(",")],
+                   [int(v) for v in a.groups.split(",")], [dt[v] for v in a.dtypes.split(",")], a.out, a.budget_s, a.rep)
+    print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    _main()

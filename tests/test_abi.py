@@ -64,7 +64,7 @@ def test_plan_families_and_invariants():
             rc, p = plan(M, 4096, 4096, bits=bits, tid=tid)
             assert rc == 0
             want = 0 if M <= dec_max else 2          # decode kernel up to its row limit, MFMA kernel beyond
-            assert p.family == want, (bits, M, p.family)
+            assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the block kernel)
             if p.family == 2:
                 assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)
             assert p.grid >= 1 and p.block % 64 == 0 and 64 <= p.block <= 1024
@@ -79,6 +79,16 @@ def test_plan_families_and_invariants():
     for M in (1, 16, 64):
         rc, p = plan(M, 512, 16384, ws=0)
         assert rc == 0 and p.splitk == 1
+    # block-tiled prefill kernel: 4-bit, enough 256 x 256 blocks for the chip, no K split
+    rc, p = plan(4096, 4096, 4096)
+    assert rc == 0 and p.family == 3 and p.grid == 256 and p.block == 512 and p.splitk == 1 and p.lds_bytes <= 160 * 1024
+    rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
+    assert rc == 0 and p.family == 2                    # 3-bit layers stay on the per-wave MFMA kernel
+    # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches
+    rc, p = plan(1, 28672, 8192)
+    assert rc == 0 and p.family == 0 and p.waves == 14 and p.kw == 1 and p.visits == 2 and p.one_shot == 0
+    rc, p = plan(1, 4096, 4096)
+    assert rc == 0 and p.family == 0 and p.one_shot == 1 and p.visits == 1 and p.waves % p.kw == 0
     # decode kernel: persistent grid never exceeds the unit groups
     rc, p = plan(1, 28672, 8192)
     assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4

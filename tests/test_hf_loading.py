@@ -160,6 +160,53 @@ def test_checkpoint_packed_for_another_gpu_is_repacked_on_load():
 
 
 @pytest.mark.gpu
+def test_checkpoint_without_extra_state_loads_as_reference_tilep():
+    """Safetensors checkpoints carry no `_extra_state`: the layer has no template id after loading and is
+    unpacked with the TileP of the reference's bundled tuned table (32 for every entry), then repacked."""
+    from flute_amd import utils
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    dtype, bits, g = torch.bfloat16, 3, 64
+    ref_tid = hf.template_id_with_tile_p(bits, hf.reference_packed_tile_p())
+    table = torch.randn(2 ** bits).to(dtype)
+    ref_model = _Tiny(dtype=dtype)
+    sd, native = {}, {}
+    for name, mod in ref_model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+            K, N = mod.in_features, mod.out_features
+            codes = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8)
+            sd[f"{name}.weight"] = utils.pack(codes, bits, [ref_tid], 108)
+            sd[f"{name}.scales"] = (torch.randn(N, K // g) / 8).to(dtype)
+            sd[f"{name}.tables"] = table
+            sd[f"{name}.tables2"] = utils.make_qmap2_from_qmap(table)
+            if mod.bias is not None:
+                sd[f"{name}.bias"] = mod.bias.detach().clone()
+            native[name] = codes
+    sd["lm_head.weight"] = ref_model.lm_head.weight.detach().clone()
+    with torch.device("meta"):
+        model = _Tiny(dtype=dtype)
+    model, _ = hf.replace_with_flute_linear(model, bits, g)
+    missing = model.load_state_dict(sd, assign=True, strict=False)
+    assert all(k.endswith("_extra_state") for k in missing.missing_keys), missing
+    model = model.to(dev)
+    assert model.layers[0].up_proj.template_id is None
+    assert hf.repack_flute_linear(model, num_sms_packed=108, example_batch_size=1) == 4
+    for name, codes in native.items():
+        lin = model.get_submodule(name)
+        assert torch.equal(utils.unpack_codes(lin.weight, bits, lin.template_id).cpu(), codes), name
+    y = model((torch.randn(2, 512) / 4).to(dtype).to(dev))
+    assert torch.isfinite(y).all()
+
+
+def test_reference_tilep_table_is_shipped():
+    assert hf.reference_packed_tile_p() == 32
+    for bits in (2, 3, 4):
+        tid = hf.template_id_with_tile_p(bits, 32)
+        import flute_amd
+        assert flute_amd.TEMPLATE_CONFIGS[(bits, tid)]["TileP"] == 32
+
+
+@pytest.mark.gpu
 def test_transformers_higgs_linear_forward_runs_on_flute_amd():
     """BASELINE.json configs[4] through its real caller: transformers' `HiggsLinear.forward`
     (integrations/higgs.py) pads x to the Hadamard block and calls `flute.tune.qgemm_v2(x, weight, scales, tables,

@@ -297,6 +297,39 @@ def test_mfma_scale_block_and_ring_paths(env):
         assert torch.equal(D1.float(), ref.to(dtype).float()), (bits, g, dtype, K, ovr)
 
 
+def test_block_prefill_kernel(env):
+    """The block-tiled prefill kernel (family 3, qgemm_block.h): 256- and 128-row blocks, ragged M (rows past M
+    read as zero and are not stored), every group size (scale blocks of 8 groups arrive by LDS-DMA), both TileP
+    layouts and dtypes, a forced grid-level K split; one-hot rows bit-exact (w^ = round_T(lut * s))."""
+    from flute_amd import dev
+    d = env.dev
+    for (tile_p, g, dtype, K, N) in [(32, 64, torch.float16, 4096, 1024), (64, 64, torch.bfloat16, 2048, 1024),
+                                     (32, 128, torch.float16, 3072, 512), (32, 32, torch.bfloat16, 1024, 256),
+                                     (64, 256, torch.float16, 4096, 256)]:
+        bits = 4
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K + N)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for M in (1, 130, 256, 700):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, splitk=2)):
+                ovr = dev.Overrides(**shp)
+                assert dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)["family"] == 3
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                err = rel_err(out, X.float() @ What)
+                assert err < tol_of(dtype), (tile_p, g, dtype, K, N, M, shp, err)
+                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert torch.equal(out1, ref1), (tile_p, g, dtype, K, N, M, shp)
+    # the planner takes it by itself where the output has enough blocks
+    assert dev.get_plan(4096, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 3
+    assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2
+
+
 # ---------------------------------------------------------------------------
 # full BASELINE shapes: size-independent properties, checker runs on the GPU
 # ---------------------------------------------------------------------------
