@@ -166,3 +166,25 @@ def test_prepare_model_flute_host_checks():
     m = torch.nn.Sequential(torch.nn.LayerNorm(8))
     prepare_model_flute("m", m, 4, 64, 1, fake=True)
     assert isinstance(m[0], torch.nn.LayerNorm)
+
+
+def test_shipped_tuned_table_is_consistent():
+    """flute_amd/data/gfx950_tuned.json (python -m flute_amd.tune on an MI355X): every entry names a template
+    the planner accepts for that problem, the headline shape is present, `_tune` answers from it without a GPU."""
+    from flute_amd import tune
+    table = tune.load_tuned_table()
+    assert len(table) > 500
+    dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}
+    for i, (key, tid) in enumerate(sorted(table.items())):
+        if i % 7:
+            continue
+        M, N, K, bits, g, num_sms, dtype, tile_p = key.split("|")
+        M, N, K, bits, g, num_sms, tile_p = map(int, (M, N, K, bits, g, num_sms, tile_p))
+        assert utils.is_template_supported(M, N, K, bits, tid, num_sms, g, dt[dtype]), key
+        if tile_p:
+            assert flute_amd.TEMPLATE_CONFIGS[(bits, tid)]["TileP"] == tile_p, key
+    assert tune.lookup_tuned(1, 4096, 4096, 4, 64, 256, torch.float16) is not None
+    assert tune.m_bucket(3) == 3 and tune.m_bucket(5) == 16 and tune.m_bucket(17) == 32 and tune.m_bucket(10 ** 6) == 4096
+    # answered from the table: no CUDA device is touched
+    tid = tune._tune(1, 4096, 4096, 4, 64, 256, torch.float16, torch.device("cpu"))
+    assert tid == tune.lookup_tuned(1, 4096, 4096, 4, 64, 256, torch.float16)
