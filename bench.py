@@ -14,12 +14,18 @@ Python op is reported separately as `eager_us_per_step`).
 Rank 0 prints ONE JSON line (contract in the task description) carrying
 `roofline` (HBM, algorithmic bytes / kernel time from HIP events on the launch
 stream) and `cpu_baseline` (the CPU oracle = the reference's test formula,
-dequant + torch.mm, timed on this host's cores).  N > 1: one process per GPU,
-independent replicas of the same layer (the path has no collective; weak
-scaling), barrier + max-over-ranks timing; the line then also carries
-`tp_mlp_pair`: BASELINE.json configs[3], the 8192x28672 projection pair sharded
-N-way (column-parallel -> row-parallel + ONE RCCL all-reduce), kernels alone and
-with the collective.  The single-GPU extras and the CPU baseline run at N=1 only.
+dequant + torch.mm, timed on this host's cores).
+
+N > 1 (one process per GPU, RCCL): the headline becomes BASELINE.json
+configs[3] - the Llama-3-70B MLP pair 8192x28672 -> 28672x8192 sharded N-way
+(column-parallel up projection, row-parallel down projection, ONE all-reduce
+of M*8192*2 B), the two launches AND the collective of 50 pairs captured in one
+hipGraph, barrier + max-over-ranks; `value` = bytes of the whole (unsharded)
+pair / that time, "scaling": "strong".  The independent-replica figure of the
+single-GPU headline (no collective, weak scaling) rides along as `replicas`.
+N = 1: the same pair at TP = 1 is an extra (`tp_mlp_pair`), together with the
+other BASELINE configs, prefill shapes with torch.mm fp16 beside them, and the
+CPU baseline.
 """
 import argparse
 import json
@@ -197,48 +203,78 @@ def cpu_baseline(N, K, bits, g, tile_p=32, runs=36):
     }
 
 
-def tp_mlp_pair(world, rank, device, dist, iters=200):
-    """BASELINE.json configs[3] on `world` GPUs: the 8192x28672 up projection N-sharded (column-parallel, no
-    collective) feeding the 28672x8192 down projection K-sharded (row-parallel, ONE all-reduce of M*8192*2 B
-    over RCCL/xGMI) - flute_amd/tp.py.  Each rank builds its own shard directly (random packed data).  Reported:
-    the two kernels alone and the pair including the all-reduce, max over ranks, eager launches."""
-    try:
-        bits, g, dtype, M, H, F = 4, 64, torch.float16, 1, 8192, 28672
-        if F % (world * 256):
-            return {"skipped": f"28672 does not split {world}-way on packed column blocks"}
-        up = Layer(M, F // world, H, bits, g, dtype, device, 4, None, seed=rank)
-        down = Layer(M, H, F // world, bits, g, dtype, device, 4, None, seed=rank)
-        up.tune()
-        down.tune()
+def tp_mlp_pair(world, rank, device, dist, pairs=50):
+    """BASELINE.json configs[3] on `world` GPUs: the Llama-3-70B MLP up projection 8192 -> 28672 N-sharded
+    (column-parallel, no collective) feeding the down projection 28672 -> 8192 K-sharded (row-parallel, ONE
+    all-reduce of M*8192*2 B over RCCL/xGMI) - flute_amd/tp.py, reference contract vllm_utils.py:224-226,
+    265-326.  Each rank builds its own shard directly (random packed data).  `pairs` pairs are captured in ONE
+    hipGraph - launches AND the all-reduce - and the replay is timed (max over ranks); the kernels alone are
+    timed the same way.  Falls back to eager launches if the collective cannot be captured."""
+    bits, g, dtype, M, H, F = 4, 64, torch.float16, 1, 8192, 28672
+    if F % (world * 256):
+        return {"skipped": f"28672 does not split {world}-way on packed column blocks"}
+    ncopies = max(2, (L3_BYTES // (2 * (bits * (F // world) // 16) * H)) // 2 + 2)
+    up = Layer(M, F // world, H, bits, g, dtype, device, ncopies, None, seed=rank)
+    down = Layer(M, H, F // world, bits, g, dtype, device, ncopies, None, seed=rank + 100)
+    up.tune()
+    down.tune()
 
-        def run(collective):
-            for i in range(10):
-                up.step(i); y = down.step(i)
-                if collective:
-                    dist.all_reduce(y)
-            torch.cuda.synchronize()
+    def body(collective, n):
+        for i in range(n):
+            up.step(i)
+            y = down.step(i)
+            if collective:
+                dist.all_reduce(y)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
             dist.barrier(device_ids=[device.index])
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for i in range(iters):
-                up.step(i); y = down.step(i)
-                if collective:
-                    dist.all_reduce(y)
-            e.record()
-            torch.cuda.synchronize()
-            t = torch.tensor([s.elapsed_time(e) / iters * 1e3], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return round(t.item(), 3)
 
-        k_us, kc_us = run(False), run(True)
-        nbytes = world * (up.bytes() + down.bytes())
-        return {"workload": f"W4G64 fp16 M=1: 8192x28672 column-parallel -> 28672x8192 row-parallel, TP={world}",
-                "kernels_us": k_us, "kernels_plus_allreduce_us": kc_us,
-                "allreduce_bytes": 2 * M * H, "launch": "eager (host launch overhead included in both)",
-                "whole_job_GBps_kernels": round(nbytes / k_us / 1e3, 1),
-                "whole_job_GBps_with_allreduce": round(nbytes / kc_us / 1e3, 1)}
-    except Exception as exc:          # never lose the headline line to the optional leg
-        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    def run(collective):
+        body(collective, 5)
+        sync()
+        mode = "hipGraph"
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body(collective, pairs)
+            graph.replay()
+            sync()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e9
+            for _ in range(3):
+                s.record(); graph.replay(); e.record()
+                torch.cuda.synchronize()
+                best = min(best, s.elapsed_time(e) / pairs * 1e3)
+                sync()
+        except Exception:                                   # noqa: BLE001 - capture of the collective unsupported
+            torch.cuda.synchronize()
+            mode = "eager"
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sync()
+            s.record(); body(collective, pairs); e.record()
+            torch.cuda.synchronize()
+            best = s.elapsed_time(e) / pairs * 1e3
+        t = torch.tensor([best], device=device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), mode
+
+    k_us, k_mode = run(False)
+    if dist is not None:
+        kc_us, c_mode = run(True)
+    else:
+        kc_us, c_mode = k_us, k_mode
+    nbytes = world * (up.bytes() + down.bytes())
+    return {"workload": f"W4G64 fp16 M=1 Llama-3-70B MLP pair: 8192x28672 column-parallel -> 28672x8192 row-parallel, TP={world}",
+            "kernels_us": round(k_us, 3), "kernels_plus_allreduce_us": round(kc_us, 3),
+            "allreduce_bytes": 2 * M * H, "launch": f"kernels: {k_mode}; with all-reduce: {c_mode}",
+            "whole_job_bytes": nbytes,
+            "whole_job_GBps_kernels": round(nbytes / k_us / 1e3, 1),
+            "whole_job_GBps_with_allreduce": round(nbytes / kc_us / 1e3, 1),
+            "frac_hbm_8TBps_per_gpu_with_allreduce": round(nbytes / kc_us / 1e3 / world / HBM_PEAK_GBPS, 4),
+            "template_ids": [up.template_id, down.template_id]}
 
 
 def main():
@@ -295,12 +331,17 @@ def main():
     hot.template_id = tid
     hot_ms, _ = time_graph(hot, args.steps, args.warmup, lambda: torch.cuda.synchronize())
 
-    tp_pair = tp_mlp_pair(world, rank, device, dist) if dist is not None else None
+    # Llama-3-70B MLP pair (configs[3]): with a process group it is the headline (strong scaling, one RCCL
+    # all-reduce inside the captured graph); on one GPU it is an extra (TP = 1, no collective)
+    try:
+        tp_pair = tp_mlp_pair(world, rank, device, dist) if (dist is not None or not args.no_extras) else None
+    except Exception as exc:          # never lose the line to this leg  # noqa: BLE001
+        tp_pair = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     extras = []
     if rank == 0 and dist is None and not args.no_extras:
         for (n, k) in ((4096, 4096), (11008, 4096)):
-            for m in (1, 16, 256) + ((4096,) if n == 4096 else ()):      # 4096: prefill, MFMA utilisation
+            for m in (1, 16, 256, 1024, 4096):                            # >= 256: prefill, MFMA utilisation
                 if (n, k, m) == (4096, 4096, 1):
                     continue
                 lay = Layer(m, n, k, bits, g, dtype, device, copies_for(n, k, bits), NF4_VALUES)
@@ -308,7 +349,21 @@ def main():
                 steps = 500 if m < 256 else (200 if m < 1024 else 60)
                 e_ms, _ = time_graph(lay, steps, 20, lambda: torch.cuda.synchronize())
                 us = e_ms / steps * 1e3
+                mm = {}
+                if m >= 256:                                              # dense fp16 GEMM of the same shape beside it
+                    wd = [torch.randn(k, n, device=device, dtype=dtype) for _ in range(max(2, L3_BYTES // (2 * k * n) + 2))]
+                    xd = torch.randn(m, k, device=device, dtype=dtype)
+
+                    class _MM:
+                        def step(self, i, wd=wd, xd=xd):
+                            return torch.mm(xd, wd[i % len(wd)])
+
+                    d_ms, _ = time_graph(_MM(), steps, 10, lambda: torch.cuda.synchronize())
+                    mm = {"torch_mm_fp16_us": round(d_ms / steps * 1e3, 3),
+                          "speedup_vs_torch_mm": round(d_ms / e_ms, 3)}
+                    del wd, xd
                 extras.append({
+                    **mm,
                     "workload": f"W4G64 fp16 M={m} K={k} N={n}", "template_id": lay.template_id,
                     "us": round(us, 3),
                     "GBps": round(lay.bytes() / us / 1e3, 1),
@@ -366,39 +421,73 @@ def main():
         torch.cuda.empty_cache()
 
     if rank == 0:
+        import flute_amd
         achieved = bytes_step / (ms_per_step * 1e-3) / 1e9
-        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_traffic.json")
+        plan = flute_amd.utils.get_plan(M, N, K, bits, g, tid, layer.num_sms, dtype)
+        # HBM bytes per launch from the committed PMC passes of THIS command (tools/prof_bench.sh writes the file
+        # together with the plan it profiled): reported only while the plan is still the one that was profiled
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        out = {
+            tj = json.load(open(tpath))
+            if tj.get("plan") == plan:
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/r02_bench_traffic.json"
+        replicas = {
             "metric": "qgemm effective GB/s, M=1, W4G64 NF4 fp16, K=N=4096 (Llama-3-8B linear), HBM-cold",
+            "value": round(value, 2), "ms_per_step": round(ms_per_step, 6), "scaling": "weak",
+            "parallelism": f"{world} independent replica(s), no collective"}
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
+            "frac_of_measured_copy_6.29TBps": round(achieved / HBM_COPY_GBPS, 4),
+            "bytes_per_launch": bytes_step,
+            "kernel_us_events": round(ms_per_step * 1e3, 3),
+            "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; traffic = "
+                    "2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction, MI355X_MICROARCH.md); a pure read of "
+                    "the same bytes in this harness takes 3.16 us (profiles/r01_calibration_stream_read.json)",
+        }
+        out = {
+            "metric": replicas["metric"],
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random codes/scales, NF4 table, X=randn/100; "
                     f"{len(layer.Q)} rotating weight copies > 256 MiB L3)",
             "config": {"workload": "W4G64 NF4 fp16 qgemm, M=1, K=4096, N=4096 (BASELINE configs[1])",
-                       "template_id": tid, "plan": __import__("flute_amd").utils.get_plan(
-                           M, N, K, bits, g, tid, layer.num_sms, dtype),
+                       "template_id": tid, "plan": plan,
                        "launch": "hipGraph replay of all steps",
-                       "parallelism": f"{world} independent replica(s), no collective"},
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "frac_of_measured_copy_6.29TBps": round(achieved / HBM_COPY_GBPS, 4),
-                "bytes_per_launch": bytes_step,
-                "kernel_us_events": round(ms_per_step * 1e3, 3),
-                "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; "
-                        "traffic = 2*FETCH_SIZE + WRITE_SIZE of profiles/r01_bench_traffic.json; a pure read "
-                        "of the same bytes in this harness takes 3.16 us (profiles/r01_calibration_stream_read.json)",
-            },
+                       "parallelism": replicas["parallelism"]},
+            "roofline": roofline,
             "cache_resident": {"us": round(hot_ms / args.steps * 1e3, 3),
                                "GBps": round(bytes_step / (hot_ms / args.steps * 1e-3) / 1e9, 1)},
             "eager_us_per_step": round(eager_ms / min(args.steps, 500) * 1e3, 3),
             "wall_ms_timed_region": round(wall_ms, 3),
             "extras": extras,
         }
+        if dist is not None and tp_pair is not None and "kernels_plus_allreduce_us" in tp_pair:
+            # N > 1: the north-star multi-GPU workload is the headline - the column-parallel / row-parallel pair
+            # with its ONE all-reduce; the replica figure of the single-GPU headline moves to `replicas`
+            t_us = tp_pair["kernels_plus_allreduce_us"]
+            per_gpu = tp_pair["whole_job_bytes"] / world
+            out.update({
+                "metric": "qgemm effective GB/s, M=1, W4G64 fp16, Llama-3-70B MLP pair 8192x28672 -> 28672x8192, "
+                          "tensor-parallel over all GPUs incl. the RCCL all-reduce, HBM-cold",
+                "value": tp_pair["whole_job_GBps_with_allreduce"], "ms_per_step": round(t_us / 1e3, 6),
+                "scaling": "strong", "steps": args.steps,
+                "config": {"workload": tp_pair["workload"] + " (BASELINE configs[3])",
+                           "template_ids": tp_pair["template_ids"], "launch": tp_pair["launch"],
+                           "parallelism": f"tp{world}: N-sharded up projection, K-sharded down projection, 1 all-reduce of "
+                                          f"{tp_pair['allreduce_bytes']} B per pair",
+                           "step": "one MLP pair (two qgemm launches + one all-reduce); the driver's --steps applies "
+                                   "to the replica leg, the pair is timed over 50 captured pairs x 3 replays"},
+                "roofline": {"bound": "hbm", "achieved": round(per_gpu / tp_pair["kernels_us"] / 1e3, 2),
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(per_gpu / tp_pair["kernels_us"] / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+                             "bytes_per_launch_pair": per_gpu, "kernel_us_events": tp_pair["kernels_us"],
+                             "note": "per GPU: algorithmic bytes of its two shards / time of the two kernels (no collective)"},
+                "replicas": replicas,
+            })
         if tp_pair is not None:
             out["tp_mlp_pair"] = tp_pair
         if dist is None and not args.no_cpu:
