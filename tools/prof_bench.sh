@@ -28,7 +28,7 @@ fetch = write = None
 kern = None
 for l in summ.splitlines():
     if l.startswith("PMC ") and "qgem" in l:
-        kern = l[4:].split(":")[0]
+        kern = l[4:].rsplit(": ", 1)[0]
         m = re.search(r"FETCH_SIZE=(\d+)", l)
         if m: fetch = int(m.group(1))
         m = re.search(r"WRITE_SIZE=(\d+)", l)
