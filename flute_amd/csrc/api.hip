@@ -305,7 +305,14 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (ov.family == kFamilyBlock) blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
         else if (M >= 512 && tiles256 * 100 >= (long)num_sms * 65) blk_cfg = 0;
         else if (M >= 512 && tiles128 * 100 >= (long)num_sms * 90 && tiles128 * 100 <= (long)num_sms * 110) blk_cfg = 1;
-        if (blk_cfg >= 0) family = kFamilyBlock;
+        if (blk_cfg >= 0) {
+            family = kFamilyBlock;
+            // cfg + 2: software-pipelined schedule (qgemm_block.h).  Measured (tools/block_lab.py, M = 4096, 4096^2):
+            // bf16 256-row blocks 147.6 vs 151.1 us, 128-row blocks fp16 169.8 vs 171.5 / bf16 203.9 vs 217.1; fp16
+            // 256-row blocks are faster in lockstep (135.4 vs 141.4).  Override: slabs_per_wave 2 forces it, 1 forbids it.
+            const bool sp = (ov.slabs == 2) || (ov.slabs != 1 && (dtype == FLUTE_BF16 || blk_cfg == 1));
+            if (sp) blk_cfg |= 2;
+        }
     }
     p->family = family;
 
@@ -315,7 +322,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
-        const int tm = blk_cfg == 0 ? 8 : 4, bm = tm * 32;
+        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / 64;
         int splitk = (ov.splitk > 0) ? ov.splitk : 1;
         const int align_k = std::max(64, 8 << lg);

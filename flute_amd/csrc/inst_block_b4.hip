@@ -8,6 +8,11 @@ BlockKernel block_kernel_b4(int dtype, int tile_p, int cfg) {
     if (tile_p == 64 && cfg == 0) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 8, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 8, 2, 4>;
     if (tile_p == 32 && cfg == 1) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 32, 4, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 32, 4, 2, 4>;
     if (tile_p == 64 && cfg == 1) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 4, 2, 4> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 4, 2, 4>;
+    // cfg 2 / 3: the same two blocks on the software-pipelined schedule
+    if (tile_p == 32 && cfg == 2) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 32, 8, 2, 4, true> : (BlockKernel)qgemm_block_kernel<BF16, 4, 32, 8, 2, 4, true>;
+    if (tile_p == 64 && cfg == 2) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 8, 2, 4, true> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 8, 2, 4, true>;
+    if (tile_p == 32 && cfg == 3) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 32, 4, 2, 4, true> : (BlockKernel)qgemm_block_kernel<BF16, 4, 32, 4, 2, 4, true>;
+    if (tile_p == 64 && cfg == 3) return dtype == 0 ? (BlockKernel)qgemm_block_kernel<F16, 4, 64, 4, 2, 4, true> : (BlockKernel)qgemm_block_kernel<BF16, 4, 64, 4, 2, 4, true>;
     return nullptr;
 }
 }  // namespace flute_amd

@@ -67,7 +67,14 @@ template <int N> __device__ __forceinline__ void blk_lookup_wait(uint32_t (&v)[8
                  : "n"(N) : "memory");
 }
 
-template <typename T, int BITS, int TILEP, int TM, int WM, int WN>
+// SP (software-pipelined schedule): the LDS work of half step p+1 - activation fragments, pair-table lookups,
+// scales - is issued BETWEEN the MFMAs of half step p (after the four MFMAs of a row tile: that row's next
+// fragment and 16 / TM lookups), so a wave's matrix pipe time covers its own LDS latency and VALU address
+// arithmetic; one s_barrier per 64-k step (mid step, when stage t has been read completely and stage t+1 is about
+// to be).  The lockstep schedule (SP = false: dequantise, then multiply, per half step) measured 40 % MFMA-busy;
+// separating the two parts by barriers and running the two waves of a SIMD half a phase apart was slower still
+// (the load part, ~1000 cycles, is longer than the 512-cycle MFMA part: tools/block_diag.py).
+template <typename T, int BITS, int TILEP, int TM, int WM, int WN, bool SP = false>
 __global__ __launch_bounds__(WM * WN * 64) void qgemm_block_kernel(const BlockArgs args) {
     static_assert(BITS == 4 || BITS == 2, "3-bit layers use the per-wave MFMA kernel (qgemm_tile.h)");
     using NT = Num<T>;
@@ -262,6 +269,124 @@ __global__ __launch_bounds__(WM * WN * 64) void qgemm_block_kernel(const BlockAr
         }
     };
 
+    // ---- software-pipelined schedule ----
+    constexpr int NLK = J * 4;                                     // lookups per half step
+    constexpr int LPR = NLK / TM;                                  // ... issued after every row tile
+    static_assert(NLK % TM == 0 && NLK == 16 && J == 4 && TM <= 8, "software-pipelined schedule: 4-bit layers");
+    uint32_t v[NLK];                                               // hidden lookups of the NEXT half step
+    u32x4_t af[TM];                                                // fragments: current, replaced row by row (hidden)
+    uint32_t scn[J];                                               // scales of the next half step (hidden)
+    // every LDS read of the loop is an inline-asm instruction with an immediate offset: one address register per
+    // 64 KB of stages instead of one per (stage, half, row tile), and no compiler-placed lgkmcnt in the MFMA stream
+    const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(wm * TM) * 1024u + aread;
+    const uint32_t frag_hi = frag_lo + 65536u;
+    const uint32_t sc_lane = sc_base + (uint32_t)r16 * 16u;
+    auto sp_scales = [&](int t, int h) {                           // -> scn (of this lane's J columns)
+        const int grp = (kbeg + t * 64 + h * 32) >> a.lg;
+        const uint32_t sb = sc_lane + (uint32_t)((grp >> 3) & 1) * 1024u * SLD + (uint32_t)(grp & 7) * 2u;
+        auto one = [&](auto j_tag) {
+            constexpr int jc = decltype(j_tag)::value;
+            uint32_t& dst = scn[jc];                               // (named first: clang does not capture through asm operands)
+            const uint32_t addr = sb;
+            asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((jc >> 2) * 1024 + (jc & 3) * 256) : "memory");
+        };
+        [&]<int... Jc>(std::integer_sequence<int, Jc...>) {
+            (one(std::integral_constant<int, Jc>{}), ...);
+        }(std::make_integer_sequence<int, J>{});
+    };
+    auto sp_lookup = [&](const u32x4_t& qw, auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;                  // lookup n: field n / 4, word n % 4
+        const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], (uint32_t)(2 * BITS * (n >> 2)), (uint32_t)(2 * BITS));
+        v[n] = lds_lookup32((idx << 7) | lane_off);
+    };
+    auto sp_frag = [&](auto slot_tag, auto h_tag, auto tm_tag) {
+        constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + decltype(tm_tag)::value) * 1024;
+        constexpr int tm = decltype(tm_tag)::value;
+        u32x4_t& dst = af[tm];
+        const uint32_t addr = off < 65536 ? frag_lo : frag_hi;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
+    };
+    auto sp_wait_lds = [&]() {                                     // releases every hidden LDS read in flight
+        if constexpr (TM == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]),
+                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4 % TM]), "+v"(af[5 % TM]),
+                           "+v"(af[6 % TM]), "+v"(af[7 % TM]), "+v"(scn[0]), "+v"(scn[1]), "+v"(scn[2]), "+v"(scn[3])
+                         : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]),
+                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2 % TM]), "+v"(af[3 % TM]),
+                           "+v"(scn[0]), "+v"(scn[1]), "+v"(scn[2]), "+v"(scn[3])
+                         : : "memory");
+        }
+    };
+    // half step p = (t, h): multiply what half step p-1 looked up, then MFMAs with the LDS work of p+1 between them
+    auto sp_half = [&](auto slot_tag, auto h_tag, int t) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int h = decltype(h_tag)::value;
+        constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;  // next half step's stage / ring slot
+        constexpr int nh = h ^ 1;
+        sp_wait_lds();                                             // lookups, fragments and scales of p are here
+        if constexpr (h == 1) {
+            // mid step: this wave has read stage t completely; batch t+1 (next ring slot) has landed once at most
+            // batch t+2 is outstanding; after the barrier stage t is free for batch t+3
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_batch(slot_tag, t + 3);
+        }
+        // a step past the end (the ring is padded to whole triples) multiplies by zero scales: its activations are
+        // the zeros of an out-of-range LDS-DMA, its weights index 0 of the table
+        const bool live = t < nsteps;
+        u32x4_t bf[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const uint32_t sj = live ? scn[j] : 0u;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) bf[j][ww] = NT::mul_scale(v[j * 4 + ww], sj);
+        }
+        sp_scales(t + h, nh);
+        const u32x4_t qw = w[nslot][nh];
+        auto row = [&](auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[R][j] = Mfma<T>::run(bf[j], af[R], acc[R][j]);
+            sp_frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (sp_lookup(qw, std::integral_constant<int, R * LPR + L>{}), ...);
+            }(std::make_integer_sequence<int, LPR>{});
+        };
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (row(std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, TM>{});
+    };
+
+    if constexpr (SP) {
+        issue_batch(std::integral_constant<int, 2>{}, 2);
+        // batch 0 and the pair table before anyone reads them
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(2 * BATCH) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        sp_scales(0, 0);
+        {
+            const u32x4_t qw = w[0][0];
+            [&]<int... R>(std::integer_sequence<int, R...>) {
+                (sp_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
+            }(std::make_integer_sequence<int, TM>{});
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (sp_lookup(qw, std::integral_constant<int, L>{}), ...);
+            }(std::make_integer_sequence<int, NLK>{});
+        }
+        for (int t0 = 0; t0 < npad; t0 += BLK_STAGES) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((sp_half(std::integral_constant<int, I>{}, std::integral_constant<int, 0>{}, t0 + I),
+                  sp_half(std::integral_constant<int, I>{}, std::integral_constant<int, 1>{}, t0 + I)), ...);
+            }(std::make_integer_sequence<int, BLK_STAGES>{});
+        }
+        sp_wait_lds();                                             // the prefetch past the end
+    } else
     for (int t0 = 0; t0 < npad; t0 += BLK_STAGES) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (step(std::integral_constant<int, I>{}, t0 + I), ...);

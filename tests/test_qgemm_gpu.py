@@ -317,7 +317,10 @@ def test_block_prefill_kernel(env):
             E = torch.zeros(M, K, dtype=dtype)
             E[torch.arange(M), ks] = 1
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
-            for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, splitk=2)):
+            # slabs_per_wave 1 / 2: lockstep / software-pipelined schedule of the same block
+            for shp in (dict(family=3, m_tiles=8, slabs_per_wave=1), dict(family=3, m_tiles=4, slabs_per_wave=1),
+                        dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=1), dict(family=3, m_tiles=8, slabs_per_wave=2),
+                        dict(family=3, m_tiles=4, slabs_per_wave=2), dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=2)):
                 ovr = dev.Overrides(**shp)
                 assert dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)["family"] == 3
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()

@@ -22,7 +22,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flute_amd", "csrc")
-UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip"]
+UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip", "inst_block_b4.hip"]
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*)\s+(\S+),")
@@ -65,7 +65,8 @@ def audit(path):
                 vm_fifo, ds_set = [], []
             continue
         text = line.strip()
-        if text.startswith("s_endpgm"):
+        if text.startswith("s_endpgm") or text.startswith("s_branch") or text.startswith("s_setpc"):
+            # what follows in layout order is not reached by falling through
             vm_fifo, ds_set = [], []
             continue
         mv = VMCNT.search(text)
@@ -74,8 +75,10 @@ def audit(path):
             if n < len(vm_fifo):
                 vm_fifo = vm_fifo[len(vm_fifo) - n:] if n > 0 else []
         ml = LGKM.search(text)
-        if ml and int(ml.group(1)) == 0:
-            ds_set = []
+        if ml:                                                 # LDS returns in order: all but the youngest N are done
+            n = int(ml.group(1))
+            if n < len(ds_set):
+                ds_set = ds_set[len(ds_set) - n:] if n > 0 else []
         if text.startswith("s_waitcnt"):
             continue
         used = regs_of(text)
@@ -83,8 +86,11 @@ def audit(path):
             ld = LOAD.match(text)
             dl = DSLOAD.match(text)
             if ld:
-                dst = regs_of(ld.group(2))
-                src = regs_of(text[ld.end():])
+                if re.search(r"\blds\s*$", text):             # LDS-DMA: the first operand is the address, no VGPR is written
+                    dst, src = set(), regs_of(text[len(ld.group(1)):])
+                else:
+                    dst = regs_of(ld.group(2))
+                    src = regs_of(text[ld.end():])
                 busy = set().union(*[r for _, r in vm_fifo]) if vm_fifo else set()
                 hit = (src | dst) & busy
                 if hit:
@@ -99,6 +105,8 @@ def audit(path):
                     findings.append((kernel, ln, text, sorted(src & busy)))
                 ds_set.append((ln, dst))
                 continue
+        if not in_asm and re.match(r"(ds_|s_load_|s_buffer_load_)", text):
+            ds_set.append((ln, set()))                         # compiler-managed LGKM operation: a slot in the queue only
         busy = set()
         for _, r in vm_fifo:
             busy |= r
