@@ -17,8 +17,8 @@ __version__ = "0.1.0"
 
 _lib.get()   # fail at import time, not at first call, when the HIP library is missing
 
-qgemm = cast(Callable[..., torch.Tensor], torch.ops.flute.qgemm_raw_simple)
-qgemm_hadamard = cast(Callable[..., torch.Tensor], torch.ops.flute.qgemm_raw_simple_hadamard)
+qgemm = cast(Callable[..., torch.Tensor], torch.ops.flute.qgemm_raw_simple.default)
+qgemm_hadamard = cast(Callable[..., torch.Tensor], torch.ops.flute.qgemm_raw_simple_hadamard.default)
 hadamard_transform = ops.hadamard_transform
 
 _QUANT_MAP_MODE = {1: "kVectorized   ", 32: "kVectorized_32", 16: "kVectorized_16", 8: "kVectorized_8 "}

@@ -55,7 +55,8 @@ at::Tensor qgemm_impl(const at::Tensor& input, const at::Tensor& weight, const a
                     workspace.device() == dev,
                 "flute::qgemm_raw_simple: all tensors must be on the input's device");
     const int64_t K = input.size(-1), N = scales.size(0);
-    at::Tensor x2d = input.reshape({-1, K});
+    const bool flat = input.dim() == 2 && input.is_contiguous();          // the decode-loop case: no view objects at all
+    at::Tensor x2d = flat ? input : input.reshape({-1, K});
     if (!x2d.is_contiguous()) x2d = x2d.contiguous();
     const int64_t M = x2d.size(0);
     at::Tensor out = at::empty({M, N}, input.options());
@@ -87,6 +88,7 @@ at::Tensor qgemm_impl(const at::Tensor& input, const at::Tensor& weight, const a
                                             (int)template_id, (int)num_sms, stream);
         TORCH_CHECK(rc == FLUTE_OK, flute_strerror(rc));      // RuntimeError with the reference's message prefixes
     }
+    if (flat) return out;
     auto shape = input.sizes().vec();
     shape.back() = N;
     return out.reshape(shape);
