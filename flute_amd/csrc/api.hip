@@ -293,26 +293,40 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     int family = (M <= dec_max) ? 0 : 2;
     if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
     else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
-    // Block-tiled prefill kernel: 4-bit layers whose output has enough 128/256 x 256 blocks to fill the chip
-    // without a K split (the fp32 partial slabs of a split would cost more than the kernel), scale rows in
-    // whole 16-B granules.  cfg 0: 256 x 256 blocks, cfg 1: 128 x 256.
+    // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
+    // columns; qgemm_block.h, the 2 x 4 wave split, stays reachable by override): 4-bit layers, scale rows in
+    // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
+    // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
+    // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
+    //   256-row block fp16 110 / 133, bf16 123 / 137;  128-row block fp16 75 / 85, bf16 89 / 92;
+    //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
     if (bits == 4 && (K >> lg) % 8 == 0 && units % 64 == 0 && K % 64 == 0 && (family == 2 || ov.family == kFamilyBlock) &&
         (ov.family < 0 || ov.family == kFamilyBlock)) {
         const long tiles256 = (long)ceil_div(M, 256) * (units / 64), tiles128 = (long)ceil_div(M, 128) * (units / 64);
-        // measured (tools/block_lab.py): 256-row blocks win from ~0.65 blocks per CU; 128-row blocks only when
-        // they give one block per CU where 256-row blocks would leave half the chip idle
-        if (ov.family == kFamilyBlock) blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
-        else if (M >= 512 && tiles256 * 100 >= (long)num_sms * 65) blk_cfg = 0;
-        else if (M >= 512 && tiles128 * 100 >= (long)num_sms * 90 && tiles128 * 100 <= (long)num_sms * 110) blk_cfg = 1;
-        if (blk_cfg >= 0) {
-            family = kFamilyBlock;
-            // cfg + 2: software-pipelined schedule (qgemm_block.h).  Measured (tools/block_lab.py, M = 4096, 4096^2):
-            // bf16 256-row blocks 147.6 vs 151.1 us, 128-row blocks fp16 169.8 vs 171.5 / bf16 203.9 vs 217.1; fp16
-            // 256-row blocks are faster in lockstep (135.4 vs 141.4).  Override: slabs_per_wave 2 forces it, 1 forbids it.
-            const bool sp = (ov.slabs == 2) || (ov.slabs != 1 && (dtype == FLUTE_BF16 || blk_cfg == 1));
-            if (sp) blk_cfg |= 2;
+        if (ov.family == kFamilyBlock) {
+            blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
+            // slabs_per_wave: 1 lockstep / 2 software-pipelined schedule of the 2 x 4 split; 3 or automatic: 1 x 8 split
+            if (ov.slabs == 2) blk_cfg |= 2;
+            else if (ov.slabs != 1) blk_cfg += 4;
+        } else if (M >= 256) {
+            const bool bf = dtype == FLUTE_BF16;
+            auto block_us = [&](long tiles, double alone, double busy) {
+                const long whole = tiles / num_sms, rest = tiles % num_sms;       // full rounds + a last partial one
+                const double last = rest == 0 ? 0.0 : (rest * 4 >= (long)num_sms * 3 ? busy : alone);
+                return ((double)whole * busy + last) * (double)K / 4096.0 + 3.0;
+            };
+            const double t256 = block_us(tiles256, bf ? 123.0 : 110.0, bf ? 137.0 : 133.0);
+            const double t128 = block_us(tiles128, bf ? 89.0 : 75.0, bf ? 92.0 : 85.0);
+            // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
+            int dbl = 0;
+            for (int m = M; m >= 512; m >>= 1) ++dbl;
+            const double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
+            if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
+            else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
         }
+        if (blk_cfg >= 0) family = kFamilyBlock;
     }
     p->family = family;
 
@@ -322,7 +336,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
-        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;
+        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;      // cfg 4: 16 row tiles per wave, the same 256-row block
         const int tiles_m = ceil_div(M, bm), tiles_n = units / 64;
         int splitk = (ov.splitk > 0) ? ov.splitk : 1;
         const int align_k = std::max(64, 8 << lg);

@@ -1,0 +1,260 @@
+// Prefill kernel, second geometry: a wave owns ALL 256 rows of the workgroup's block and 32 of its 256 columns.
+//
+// qgemm_block.h splits the 256 x 256 block 2 x 4 over the waves: each weight is dequantised by two waves, and a
+// half step carries 16 lookups + 16 multiplies for 32 MFMAs per wave; that kernel is bound by a wave's in-order
+// issue stream (~145 instructions per half step), not by a pipe.  Here the block is split 1 x 8:
+// a wave multiplies 16 row tiles by TWO column tiles = 8 units x 4 fields, so every weight of the block is
+// dequantised exactly once (8 lookups + 8 multiplies per 32 MFMAs).  Lane (r16, q4) holds the words 4 q4 .. 4 q4 + 3
+// of unit r16 % 8 and feeds MFMA weight row r16 of column tile t with field r16 / 8 + 2 t, i.e. lanes r16 and
+// r16 + 8 load the same 16 B (one cache line less per request, not one more).
+// Activation fragments: 16 row tiles per half step through EIGHT register slots - the fragment of row tile R + 8
+// replaces row tile R's as soon as its two MFMAs are issued (hidden ds_read_b128 with immediate offsets, 8 row
+// tiles = 16 MFMAs of lookahead, released by a counted lgkmcnt per row tile); the next half step's lookups and scales ride between the MFMAs of row tiles
+// 8..15.  Two barriers per 64-k step: (A) at its start - every wave has retired its reads of stage t-1, batch t+2
+// may overwrite it; (B) at mid step - every wave's batch t+1 has landed, stage t+1 may be read.
+// Same arithmetic contract as qgemm_block.h: w^ = round_T(lut * s), fp32 accumulation, one output rounding.
+#pragma once
+#include "qgemm_block.h"
+
+namespace flute_amd {
+
+// RT = 16: 256-row blocks as described; RT = 8: 128-row blocks (all eight fragments live in the slots, each replaced
+// by the NEXT half step's fragment of the same row tile; half the stage size, for outputs with too few 256-row blocks).
+template <typename T, int TILEP, int RT = 16>
+__global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args) {
+    using NT = Num<T>;
+    constexpr int BITS = 4;
+    static_assert(RT == 16 || RT == 8, "row tiles per block");
+    constexpr int NW = 8, BM = RT * 16, NT2 = 2;                   // waves, rows, column tiles per wave
+    constexpr int PIECES = RT * 2, PPW = PIECES / NW;
+    constexpr int BATCH = PPW + 2 + 1;                             // X pieces, two weight pieces, one scale block
+    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
+    constexpr int STAGE_BYTES = PIECES * 1024;
+
+    BlockArgs a = args;
+    {
+#define FLUTE_OPAQUE(x) asm volatile("" : "+s"(x))
+        FLUTE_OPAQUE(a.A); FLUTE_OPAQUE(a.Q); FLUTE_OPAQUE(a.D); FLUTE_OPAQUE(a.S); FLUTE_OPAQUE(a.QM2);
+        FLUTE_OPAQUE(a.partial); FLUTE_OPAQUE(a.M); FLUTE_OPAQUE(a.N); FLUTE_OPAQUE(a.K); FLUTE_OPAQUE(a.G);
+        FLUTE_OPAQUE(a.lg); FLUTE_OPAQUE(a.tiles_m); FLUTE_OPAQUE(a.tiles_n); FLUTE_OPAQUE(a.splitk);
+        FLUTE_OPAQUE(a.k_per_split); FLUTE_OPAQUE(a.order);
+#undef FLUTE_OPAQUE
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r16 = lane & 15;
+    const int q4 = lane >> 4;
+    const int u8 = lane & 7;                                       // this lane's unit within the wave's 8
+    const int fsel = (lane >> 3) & 1;                              // ... and field of column tile 0 (tile 1: + 2)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bid = blockIdx.x, split = 0;
+    if (a.splitk > 1) { split = bid % a.splitk; bid /= a.splitk; }
+    int tm_idx, tn_idx;
+    if (a.order == 1) {
+        const int per = a.tiles_m >> 3, x = bid & 7, i = bid >> 3;
+        tm_idx = x * per + i % per;
+        tn_idx = i / per;
+    } else if (a.order == 2) {
+        const int per = a.tiles_n >> 3, x = bid & 7, i = bid >> 3;
+        tn_idx = x * per + i % per;
+        tm_idx = i / per;
+    } else {
+        tm_idx = bid % a.tiles_m;
+        tn_idx = bid / a.tiles_m;
+    }
+    const int m0 = tm_idx * BM;
+    const int unit0 = (tn_idx * NW + wave) * 8;                    // this wave's 8 units
+    const int kbeg = split * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nsteps = (kend - kbeg) >> 6;
+    const int npad = (nsteps + BLK_STAGES - 1) / BLK_STAGES * BLK_STAGES;
+    const uint32_t row_bytes = (uint32_t)a.K * 2u;
+
+    const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
+    const srd_t w_srd = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit0 * row_bytes, 8u * row_bytes);
+    const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
+    // Activations: this wave's PPW pieces are consecutive row tiles of one half (piece p = wave * PPW + i).  Rows
+    // past M need no flag: their byte offset is past the descriptor's range (voffset is what the range check
+    // covers) and reads as zero; the K offset of a step travels in the scalar offset.
+    constexpr int PH = PPW;                                        // pieces per wave, all of half (wave * PPW) / RT
+    const int p0 = wave * PPW;
+    const uint32_t x_v0 = (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
+                                      ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2);
+    const uint32_t x_dv = 16u * row_bytes;                         // next row tile
+    const uint32_t x_lds0 = (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u;
+    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)q4 * 16u;
+    // scale block: lane L < 32 fetches 8 groups of column (unit L % 8, field L / 8); the image is lane-linear
+    const uint32_t s_voff = (lane < 32)
+        ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 7)) + (lane >> 3) * TILEP) * a.G) * 2) : 0x80000000u;
+    const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
+    const uint32_t sc_sink = sc_base + 2048u;
+
+    u32x4_t w[BLK_STAGES][2];
+    // batch u = every hidden load of K step u.  A step past the end (the ring is padded to whole triples) re-reads
+    // the last step: its products are multiplied by zero scales below.  No per-lane arithmetic: every K offset is
+    // wave-uniform and travels in the scalar offset.
+    auto issue_batch = [&](auto slot_tag, int u) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
+#pragma unroll
+        for (int i = 0; i < PH; ++i)
+            dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) w[slot][h] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)h * 64u);
+        const int g = (int)(k0 >> a.lg);
+        const bool blk_start = (u < nsteps) && ((g & 7) == 0 || u == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
+        // the block lands in this wave's image when the step starts one, else (same request) in the sink
+        dma16_buf(s_voff, s_srd, (uint32_t)((g >> 3) * 16),
+                  blk_start ? sc_base + (uint32_t)((g >> 3) & 1) * 1024u : sc_sink);
+    };
+
+    issue_batch(std::integral_constant<int, 0>{}, 0);
+    issue_batch(std::integral_constant<int, 1>{}, 1);
+    {
+        constexpr int ENT = 1 << (2 * BITS);
+        for (int p = tid; p < ENT * 8; p += NW * 64) {
+            const uint32_t v = a.QM2[p >> 3];
+            *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(v, v, v, v);
+        }
+    }
+    const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
+    const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(r16 * 4 + (q4 ^ blk_swz(r16))) * 16u;
+    const uint32_t frag_hi = frag_lo + 65536u;
+    const uint32_t sc_lane = sc_base + (uint32_t)(fsel * 8 + u8) * 16u;
+    const uint32_t shift0 = (uint32_t)fsel * 8u;                   // bit offset of this lane's field, column tile 0
+
+    f32x4_t acc[RT][NT2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t v[8];                                                 // hidden lookups of the NEXT half step: [tile][word]
+    u32x4_t af[8];                                                 // fragment slots (row tile R lives in slot R % 8)
+    uint32_t scn[NT2];                                             // scales of the next half step
+
+    auto scales = [&](int t, int h) {
+        const int grp = (kbeg + t * 64 + h * 32) >> a.lg;
+        const uint32_t sb = sc_lane + (uint32_t)((grp >> 3) & 1) * 1024u + (uint32_t)(grp & 7) * 2u;
+        uint32_t& d0 = scn[0];
+        uint32_t& d1 = scn[1];
+        asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
+        asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");     // field + 2 = 16 lanes on
+    };
+    auto lookup = [&](const u32x4_t& qw, auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;                  // tile n / 4, word n % 4
+        const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(16 * (n >> 2)), 8u);
+        v[n] = lds_lookup32((idx << 7) | lane_off);
+    };
+    auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
+        constexpr int R = decltype(r_tag)::value;
+        constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + R) * 1024;
+        u32x4_t& dst = af[R & 7];
+        const uint32_t addr = off < 65536 ? frag_lo : frag_hi;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
+    };
+    auto wait_lds = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                       "+v"(scn[0]), "+v"(scn[1])
+                     : : "memory");
+    };
+
+    auto half = [&](auto slot_tag, auto h_tag, int t) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int h = decltype(h_tag)::value;
+        constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;
+        constexpr int nh = h ^ 1;
+        wait_lds();
+        if constexpr (h == 0) {
+            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free
+            issue_batch(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, t + 2);
+        } else {
+            // (B) batch t+1 has landed once at most batch t+2 is outstanding
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const bool live = t < nsteps;                              // a step past the end multiplies by zero scales
+        u32x4_t bf[NT2];
+#pragma unroll
+        for (int c = 0; c < NT2; ++c) {
+            const uint32_t sj = live ? scn[c] : 0u;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], sj);
+        }
+        scales(t + h, nh);
+        const u32x4_t qw = w[nslot][nh];
+        auto row = [&](auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+            if constexpr (R >= 8) {
+                // row tile R's fragment was requested after row tile R-8's MFMAs of THIS half step.  LDS returns in
+                // order; younger than it: the fragments of row tiles R+1..15 and the two requests (fragment, lookup)
+                // each of row tiles 8..R-1 = 7 + (R - 8) operations
+                u32x4_t& slot_reg = af[R & 7];
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(slot_reg) : "n"(7 + (R - 8)) : "memory");
+            }
+#pragma unroll
+            for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R & 7], acc[R][c]);
+            if constexpr (RT == 16 && R < 8) {
+                frag(slot_tag, h_tag, std::integral_constant<int, R + 8>{});
+            } else {
+                frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, std::integral_constant<int, R & 7>{});
+                lookup(qw, std::integral_constant<int, R & 7>{});
+            }
+        };
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (row(std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, RT>{});
+    };
+
+    // batch 0 and the pair table before anyone reads them
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(BATCH) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    scales(0, 0);
+    {
+        const u32x4_t qw = w[0][0];
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
+            (lookup(qw, std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, 8>{});
+    }
+    for (int t0 = 0; t0 < npad; t0 += BLK_STAGES) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((half(std::integral_constant<int, I>{}, std::integral_constant<int, 0>{}, t0 + I),
+              half(std::integral_constant<int, I>{}, std::integral_constant<int, 1>{}, t0 + I)), ...);
+        }(std::make_integer_sequence<int, BLK_STAGES>{});
+    }
+    wait_lds();                                                    // the prefetch past the end
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
+
+    // ---- epilogue: accumulator register i of lane (r16, q4) = weight row 4 q4 + i of the column tile = unit
+    // (4 q4 + i) % 8, field q4 / 2 + 2 t: four consecutive columns; the lane's output row is r16 ----
+    const int c_unit = unit0 + (q4 & 1) * 4;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int row = m0 + r * 16 + r16;
+        if (row < a.M) {
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const int col = unit_col0<BITS, TILEP>(c_unit) + ((q4 >> 1) + 2 * t) * TILEP;
+                const f32x4_t o4 = acc[r][t];
+                if (a.splitk == 1) {
+                    uint2 o;
+                    o.x = (uint32_t)NT::from_float(o4[0]) | ((uint32_t)NT::from_float(o4[1]) << 16);
+                    o.y = (uint32_t)NT::from_float(o4[2]) | ((uint32_t)NT::from_float(o4[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col) = o;
+                } else {
+                    *reinterpret_cast<f32x4_t*>(a.partial + ((size_t)split * a.M + row) * a.N + col) = o4;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace flute_amd

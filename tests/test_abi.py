@@ -82,6 +82,11 @@ def test_plan_families_and_invariants():
     # block-tiled prefill kernel: 4-bit, enough 256 x 256 blocks for the chip, no K split
     rc, p = plan(4096, 4096, 4096)
     assert rc == 0 and p.family == 3 and p.grid == 256 and p.block == 512 and p.splitk == 1 and p.lds_bytes <= 160 * 1024
+    assert p.m_block == 4                               # 256-row blocks, 1 x 8 wave split (qgemm_block2.h)
+    rc, p = plan(2048, 4096, 4096)
+    assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 256      # 128-row blocks: one per CU
+    rc, p = plan(1024, 4096, 4096)
+    assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel is faster
     rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # 3-bit layers stay on the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches

@@ -317,8 +317,11 @@ def test_block_prefill_kernel(env):
             E = torch.zeros(M, K, dtype=dtype)
             E[torch.arange(M), ks] = 1
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
-            # slabs_per_wave 1 / 2: lockstep / software-pipelined schedule of the same block
-            for shp in (dict(family=3, m_tiles=8, slabs_per_wave=1), dict(family=3, m_tiles=4, slabs_per_wave=1),
+            # slabs_per_wave 3 (what the planner takes): 1 x 8 wave split (qgemm_block2.h); 1 / 2: lockstep /
+            # software-pipelined schedule of the 2 x 4 split (qgemm_block.h)
+            for shp in (dict(family=3, m_tiles=8, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3),
+                        dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=3), dict(family=3, m_tiles=4, splitk=2, slabs_per_wave=3),
+                        dict(family=3, m_tiles=8, slabs_per_wave=1), dict(family=3, m_tiles=4, slabs_per_wave=1),
                         dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=1), dict(family=3, m_tiles=8, slabs_per_wave=2),
                         dict(family=3, m_tiles=4, slabs_per_wave=2), dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=2)):
                 ovr = dev.Overrides(**shp)
@@ -329,7 +332,10 @@ def test_block_prefill_kernel(env):
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1, ref1), (tile_p, g, dtype, K, N, M, shp)
     # the planner takes it by itself where the output has enough blocks
-    assert dev.get_plan(4096, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 3
+    p = dev.get_plan(4096, 4096, 4096, 4, 64, 16, 256, torch.float16)
+    assert p["family"] == 3 and p["m_block"] == 4 and p["grid"] == 256, p           # 256-row blocks, 1 x 8 split
+    p = dev.get_plan(2048, 4096, 4096, 4, 64, 16, 256, torch.bfloat16)
+    assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 256, p           # 128-row blocks fill the chip
     assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2
 
 
