@@ -298,7 +298,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
-    //   256-row block fp16 110 / 133, bf16 123 / 137;  128-row block fp16 75 / 85, bf16 89 / 92;
+    //   256-row block fp16 109 / 129, bf16 125 / 136;  128-row block fp16 74 / 81, bf16 80 / 88;
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
     if (bits == 4 && (K >> lg) % 8 == 0 && units % 64 == 0 && K % 64 == 0 && (family == 2 || ov.family == kFamilyBlock) &&
@@ -316,8 +316,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 const double last = rest == 0 ? 0.0 : (rest * 4 >= (long)num_sms * 3 ? busy : alone);
                 return ((double)whole * busy + last) * (double)K / 4096.0 + 3.0;
             };
-            const double t256 = block_us(tiles256, bf ? 123.0 : 110.0, bf ? 137.0 : 133.0);
-            const double t128 = block_us(tiles128, bf ? 89.0 : 75.0, bf ? 92.0 : 85.0);
+            const double t256 = block_us(tiles256, bf ? 125.0 : 109.0, bf ? 136.0 : 129.0);
+            const double t128 = block_us(tiles128, bf ? 80.0 : 74.0, bf ? 88.0 : 81.0);
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
             int dbl = 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const int kbeg = split * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg) >> 6;
-    const int npad = (nsteps + BLK_STAGES - 1) / BLK_STAGES * BLK_STAGES;
     const uint32_t row_bytes = (uint32_t)a.K * 2u;
 
     const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
@@ -94,9 +93,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const uint32_t sc_sink = sc_base + 2048u;
 
     u32x4_t w[BLK_STAGES][2];
-    // batch u = every hidden load of K step u.  A step past the end (the ring is padded to whole triples) re-reads
-    // the last step: its products are multiplied by zero scales below.  No per-lane arithmetic: every K offset is
-    // wave-uniform and travels in the scalar offset.
+    // batch u = every hidden load of K step u.  Batches past the end (issued two steps ahead, never consumed)
+    // re-read the last step.  No per-lane arithmetic: every K offset is wave-uniform and travels in the scalar offset.
     auto issue_batch = [&](auto slot_tag, int u) {
         constexpr int slot = decltype(slot_tag)::value;
         const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
@@ -179,11 +177,10 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
             asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
             __builtin_amdgcn_s_barrier();
         }
-        const bool live = t < nsteps;                              // a step past the end multiplies by zero scales
         u32x4_t bf[NT2];
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
-            const uint32_t sj = live ? scn[c] : 0u;
+            const uint32_t sj = scn[c];
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], sj);
         }
@@ -224,11 +221,20 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
             (lookup(qw, std::integral_constant<int, R>{}), ...);
         }(std::make_integer_sequence<int, 8>{});
     }
-    for (int t0 = 0; t0 < npad; t0 += BLK_STAGES) {
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((half(std::integral_constant<int, I>{}, std::integral_constant<int, 0>{}, t0 + I),
-              half(std::integral_constant<int, I>{}, std::integral_constant<int, 1>{}, t0 + I)), ...);
-        }(std::make_integer_sequence<int, BLK_STAGES>{});
+    // The ring slots are compile-time, so the step loop is unrolled by three - and left after the LAST step, not
+    // after a whole triple (K = 4096 = 64 steps would otherwise run 66).  What is in flight at the exit (the
+    // clamped batches nsteps, nsteps + 1 and the prefetch for step nsteps) is dead and drained below.
+    auto step = [&](auto slot_tag, int t) {
+        half(slot_tag, std::integral_constant<int, 0>{}, t);
+        half(slot_tag, std::integral_constant<int, 1>{}, t);
+    };
+    for (int t0 = 0;; t0 += BLK_STAGES) {
+        step(std::integral_constant<int, 0>{}, t0);
+        if (t0 + 1 >= nsteps) break;
+        step(std::integral_constant<int, 1>{}, t0 + 1);
+        if (t0 + 2 >= nsteps) break;
+        step(std::integral_constant<int, 2>{}, t0 + 2);
+        if (t0 + 3 >= nsteps) break;
     }
     wait_lds();                                                    // the prefetch past the end
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
