@@ -336,7 +336,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
-        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;      // cfg 4: 16 row tiles per wave, the same 256-row block
+        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;      // block rows / 32
         const int tiles_m = ceil_div(M, bm), tiles_n = units / 64;
         int splitk = (ov.splitk > 0) ? ov.splitk : 1;
         const int align_k = std::max(64, 8 << lg);

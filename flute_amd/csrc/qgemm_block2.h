@@ -18,13 +18,16 @@
 
 namespace flute_amd {
 
-// RT = 16: 256-row blocks as described; RT = 8: 128-row blocks (all eight fragments live in the slots, each replaced
-// by the NEXT half step's fragment of the same row tile; half the stage size, for outputs with too few 256-row blocks).
+// RT = 16: 256-row blocks as described; RT = 8 / 4: 128- / 64-row blocks (every fragment lives in a slot, each replaced
+// by the NEXT half step's fragment of the same row tile; smaller stages, for outputs with too few 256-row blocks).
 template <typename T, int TILEP, int RT = 16>
 __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args) {
     using NT = Num<T>;
     constexpr int BITS = 4;
-    static_assert(RT == 16 || RT == 8, "row tiles per block");
+    // (RT = 4, 64-row blocks, works too but a block then takes 87 % of a 128-row block's time for half its work:
+    // the per-step costs - 8 lookups per wave, the DMA queue, two barriers - do not shrink with the rows; not instantiated)
+    static_assert(RT == 16 || RT == 8 || RT == 4, "row tiles per block");
+    constexpr int NS = RT < 8 ? RT : 8;                            // fragment slots
     constexpr int NW = 8, BM = RT * 16, NT2 = 2;                   // waves, rows, column tiles per wave
     constexpr int PIECES = RT * 2, PPW = PIECES / NW;
     constexpr int BATCH = PPW + 2 + 1;                             // X pieces, two weight pieces, one scale block
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint32_t v[8];                                                 // hidden lookups of the NEXT half step: [tile][word]
-    u32x4_t af[8];                                                 // fragment slots (row tile R lives in slot R % 8)
+    u32x4_t af[NS];                                                // fragment slots (row tile R lives in slot R % 8)
     uint32_t scn[NT2];                                             // scales of the next half step
 
     auto scales = [&](int t, int h) {
@@ -156,11 +159,18 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
     };
     auto wait_lds = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
-                       "+v"(scn[0]), "+v"(scn[1])
-                     : : "memory");
+        if constexpr (NS == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4 % NS]), "+v"(af[5 % NS]),
+                           "+v"(af[6 % NS]), "+v"(af[7 % NS]), "+v"(scn[0]), "+v"(scn[1])
+                         : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(scn[0]), "+v"(scn[1])
+                         : : "memory");
+        }
     };
 
     auto half = [&](auto slot_tag, auto h_tag, int t) {
@@ -201,7 +211,12 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
                 frag(slot_tag, h_tag, std::integral_constant<int, R + 8>{});
             } else {
                 frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, std::integral_constant<int, R & 7>{});
-                lookup(qw, std::integral_constant<int, R & 7>{});
+                if constexpr (RT == 4) {                           // 8 lookups over 4 row tiles
+                    lookup(qw, std::integral_constant<int, 2 * R>{});
+                    lookup(qw, std::integral_constant<int, 2 * R + 1>{});
+                } else {
+                    lookup(qw, std::integral_constant<int, R & 7>{});
+                }
             }
         };
         [&]<int... R>(std::integer_sequence<int, R...>) {
@@ -218,7 +233,9 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         const u32x4_t qw = w[0][0];
         [&]<int... R>(std::integer_sequence<int, R...>) {
             (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
-            (lookup(qw, std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, NS>{});
+        [&]<int... L>(std::integer_sequence<int, L...>) {
+            (lookup(qw, std::integral_constant<int, L>{}), ...);
         }(std::make_integer_sequence<int, 8>{});
     }
     // The ring slots are compile-time, so the step loop is unrolled by three - and left after the LAST step, not

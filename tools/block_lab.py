@@ -84,7 +84,8 @@ def check():
 
 def timing():
     for (M, N, K) in ((4096, 4096, 4096), (1024, 4096, 4096), (1024, 11008, 4096), (2048, 4096, 4096), (4096, 11008, 4096),
-                      (512, 11008, 4096), (256, 11008, 4096), (512, 4096, 4096), (2048, 11008, 4096), (1024, 8192, 8192), (512, 28672, 8192)):
+                      (512, 11008, 4096), (256, 11008, 4096), (512, 4096, 4096), (2048, 11008, 4096), (1024, 8192, 8192), (512, 28672, 8192),
+                      (256, 4096, 4096), (256, 28672, 8192), (256, 8192, 8192), (128, 11008, 4096), (128, 28672, 8192)):
         for dtype in (f16, bf16):
             for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, slabs_per_wave=2),
                         dict(family=3, m_tiles=4, slabs_per_wave=2), dict(family=3, m_tiles=8, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3), dict()):
