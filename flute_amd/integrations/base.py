@@ -3,9 +3,16 @@
 Same constructor, buffers (`weight[P,K] int16`, `scales[N,G]`, `tables[2^b]`,
 `tables2`), extra-state and forward semantics (in-place bias add) as the
 reference.  `prepare_model_flute` is the model-walking NormalFloat quantizer of
-base.py:44-200 for plain `nn.Linear` layers (the bitsandbytes / learnable-scale
-sources and the CLI of base.py:329-388 are outside the hot path).
+base.py:44-200 for plain `nn.Linear` layers; `quantize_hf_model` and the module's
+command line are the checkpoint quantizer of base.py:329-388 (the bitsandbytes /
+learnable-scale sources stay outside the hot path).
+
+    python -m flute_amd.integrations.base --pretrained_model_name_or_path DIR --save_directory OUT \
+        --num_bits 4 --group_size 64 --torch_dtype float16 --example_batch_size 1
 """
+import argparse
+import json
+import os
 import warnings
 from typing import Dict, Optional
 
@@ -13,6 +20,8 @@ import torch
 
 import flute_amd
 import flute_amd.utils
+
+FLUTE_CONFIG_FILE_NAME = "flute_config.json"        # flute/integrations/base.py:24
 
 
 class FluteLinear(torch.nn.Module):
@@ -162,3 +171,54 @@ def prepare_model_flute(name: str, module: torch.nn.Module, num_bits: int, group
     if not fake:
         warnings.warn("prepare_model_flute tunes every distinct layer shape on the GPU (a few seconds each)")
     _replace(name, module)
+
+
+def quantize_hf_model(pretrained_model_name_or_path: str, save_directory: str, num_bits: int, group_size: int,
+                      torch_dtype: str = "auto", example_batch_size: int = 1, fake: bool = False,
+                      device: Optional[torch.device] = None) -> None:
+    """NormalFloat-quantize the decoder layers of a Hugging Face causal LM and save the checkpoint plus
+    `flute_config.json` (flute/integrations/base.py:329-367).  The reference restricts itself to Llama and Gemma-2
+    (`isinstance` check, :343); here any `*ForCausalLM` that keeps its blocks in `model.model.layers` is accepted.
+    Quantization, tuning and packing run on the GPU (`prepare_model_flute`); the embedding and `lm_head` stay as
+    they are, as in the reference (only `model.model.layers` is walked)."""
+    from transformers import AutoModelForCausalLM
+
+    dtype = torch_dtype if torch_dtype == "auto" else getattr(torch, torch_dtype)
+    model = AutoModelForCausalLM.from_pretrained(pretrained_model_name_or_path, device_map="cpu", torch_dtype=dtype)
+    layers = getattr(getattr(model, "model", None), "layers", None)
+    if layers is None:
+        raise NotImplementedError(f"{type(model).__name__}: no `model.layers` to quantize")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    layers.to(dev)
+    prepare_model_flute(name="model.model.layers", module=layers, num_bits=num_bits, group_size=group_size,
+                        example_batch_size=example_batch_size, fake=fake)
+    # A safetensors checkpoint cannot carry the layers' extra state (the template id = the TileP the weights were
+    # packed with).  Checkpoints are therefore stored in the layout every entry of the reference's tuned table uses
+    # (TileP 32, flute_amd/data/ref_packed_tilep.json): loadable with or without extra state, here
+    # (integrations/huggingface.py re-tunes and repacks on load) and by the reference.
+    if not fake:
+        from flute_amd.integrations.huggingface import reference_packed_tile_p, template_id_with_tile_p
+        canon = template_id_with_tile_p(num_bits, reference_packed_tile_p())
+        for m in layers.modules():
+            if isinstance(m, FluteLinear) and flute_amd.TEMPLATE_CONFIGS[(num_bits, m.template_id)]["TileP"] != reference_packed_tile_p():
+                codes = flute_amd.utils.unpack_codes(m.weight, num_bits, m.template_id)
+                m.weight.copy_(flute_amd.utils.pack(codes, num_bits, [canon], flute_amd.utils.get_device_num_sms(m.weight.device)))
+                m.template_id = canon
+    state = {k: v for k, v in model.state_dict().items() if not k.endswith("_extra_state")}
+    model.save_pretrained(save_directory, state_dict=state)
+    with open(os.path.join(save_directory, FLUTE_CONFIG_FILE_NAME), "w") as f:
+        json.dump({"version": flute_amd.__version__, "num_bits": num_bits, "group_size": group_size}, f)
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--pretrained_model_name_or_path", type=str, required=True)
+    parser.add_argument("--save_directory", type=str, required=True)
+    parser.add_argument("--num_bits", type=int, required=True)
+    parser.add_argument("--group_size", type=int, required=True)
+    parser.add_argument("--torch_dtype", type=str, default="auto")
+    parser.add_argument("--example_batch_size", type=int, default=1)
+    parser.add_argument("--fake", action="store_true")
+    args = parser.parse_args()
+    quantize_hf_model(args.pretrained_model_name_or_path, args.save_directory, args.num_bits, args.group_size,
+                      args.torch_dtype, args.example_batch_size, args.fake)

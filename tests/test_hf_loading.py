@@ -1,6 +1,9 @@
 """Load-time path of a FLUTE checkpoint (flute_amd/integrations/huggingface.py; reference
 flute/integrations/huggingface.py:84-236): module replacement and the transformers registration on CPU,
 the repack of a foreign-GPU checkpoint on the GPU."""
+import os
+
+import flute_amd
 import pytest
 import torch
 
@@ -247,3 +250,53 @@ def test_transformers_higgs_linear_forward_runs_on_flute_amd():
     err = ((y.cpu().double() - ref).norm() / ref.norm()).item()
     assert err < 3e-3, err
     assert flute_amd.qgemm_hadamard is not None
+
+
+@pytest.mark.gpu
+def test_quantize_hf_model_cli_round_trip(tmp_path):
+    """flute/integrations/base.py:329-388: quantize a (tiny, random) Llama checkpoint with the command-line
+    quantizer, load the saved checkpoint into a model whose linears were replaced by empty FluteLinear layers,
+    repack for this GPU, and compare the logits with the kernel-faithful fake quantization of the same model."""
+    transformers = pytest.importorskip("transformers")
+    import json
+    import subprocess
+    import sys
+    from safetensors.torch import load_file
+    from flute_amd.integrations import base
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                                   num_attention_heads=4, num_key_value_heads=4, vocab_size=256,
+                                   max_position_embeddings=128)
+    src, out, fake = tmp_path / "fp16", tmp_path / "flute", tmp_path / "fake"
+    transformers.LlamaForCausalLM(cfg).to(torch.float16).save_pretrained(src)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "flute_amd.integrations.base", "--pretrained_model_name_or_path", str(src),
+                        "--save_directory", str(out), "--num_bits", "4", "--group_size", "64", "--torch_dtype", "float16",
+                        "--example_batch_size", "1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.load(open(out / base.FLUTE_CONFIG_FILE_NAME)) == {"version": flute_amd.__version__, "num_bits": 4, "group_size": 64}
+    base.quantize_hf_model(str(src), str(fake), 4, 64, "float16", 1, fake=True)
+
+    dev = torch.device("cuda:0")
+    state = {}
+    for f in sorted(os.listdir(out)):
+        if f.endswith(".safetensors"):
+            state.update(load_file(str(out / f)))
+    assert not any(k.endswith("_extra_state") for k in state)
+    assert state["model.layers.0.mlp.down_proj.weight"].dtype == torch.int16
+    model = transformers.LlamaForCausalLM(cfg).to(torch.float16)
+    hf.replace_with_flute_linear(model.model.layers, 4, 64, modules_to_not_convert=[])
+    for m in model.modules():                                   # materialise the empty layers, then load
+        if isinstance(m, FluteLinear):
+            m.to_empty(device=dev)
+    model.to(dev)
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    assert not unexpected and all(k.endswith("_extra_state") or "lm_head" in k for k in missing), (missing, unexpected)
+    assert hf.repack_flute_linear(model, num_sms_packed=108) == 14          # 2 layers x 7 linears
+    ref = transformers.AutoModelForCausalLM.from_pretrained(str(fake), torch_dtype=torch.float16).to(dev)
+    ids = torch.randint(0, 256, (2, 16), device=dev)
+    with torch.no_grad():
+        a = model(ids).logits.float()
+        b = ref(ids).logits.float()
+    err = ((a - b).norm() / b.norm()).item()
+    assert err < 5e-3, err
