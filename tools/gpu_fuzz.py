@@ -34,14 +34,14 @@ for case in range(ncases):
     g = rng.choice([32, 64, 64, 128, 256])
     dtype = rng.choice([torch.float16, torch.bfloat16])
     blk = tile_p * (16 if bits == 3 else 16 // bits)
-    N = blk * rng.choice([1, 2, 3, 4, 7, 8, 16])
+    N = blk * rng.choice([1, 2, 3, 4, 7, 8, 16, 16, 32, 43, 64])
     K = g * rng.randint(1, max(1, 8192 // g))
     K = (K + 63) // 64 * 64
     if K % g:
         K = (K // g + 1) * g
         if K % 64:
             K = K * 64 // __import__("math").gcd(K, 64)
-    M = rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256, 300])
+    M = rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256, 300, 512, 700, 1024, 2048, 2100])
     torch.manual_seed(case)
     W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=dev)
     S = torch.randn(N, K // g, device=dev).to(dtype)
@@ -79,5 +79,6 @@ for case in range(ncases):
 print(f"fuzz: {ran - len(fails)}/{ran} executed cases ok ({ncases - ran} skipped draws) in {time.time() - t0:.1f}s; max rel err {maxerr}")
 print("plans exercised (family, R or rows/pass, MT, SW):", sorted(fam.items()))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump({"cases": ncases, "fails": fails}, open("gpurun_out/fuzz.json", "w"), indent=1, default=str)
+json.dump({"cases": ncases, "executed": ran, "fails": fails, "max_rel_err": maxerr,
+           "plans": {str(k): v for k, v in sorted(fam.items())}}, open("gpurun_out/fuzz.json", "w"), indent=1, default=str)
 sys.exit(1 if fails else 0)
