@@ -341,7 +341,7 @@ def main():
     extras = []
     if rank == 0 and dist is None and not args.no_extras:
         for (n, k) in ((4096, 4096), (11008, 4096)):
-            for m in (1, 16, 256, 1024, 4096):                            # >= 256: prefill, MFMA utilisation
+            for m in (1, 16, 256, 1024, 2048, 4096):                      # >= 256: prefill, MFMA utilisation
                 if (n, k, m) == (4096, 4096, 1):
                     continue
                 lay = Layer(m, n, k, bits, g, dtype, device, copies_for(n, k, bits), NF4_VALUES)
