@@ -203,7 +203,7 @@ def cpu_baseline(N, K, bits, g, tile_p=32, runs=36):
     }
 
 
-def tp_mlp_pair(world, rank, device, dist, pairs=50):
+def tp_mlp_pair(world, rank, device, dist, pairs=50, warmup=5):
     """BASELINE.json configs[3] on `world` GPUs: the Llama-3-70B MLP up projection 8192 -> 28672 N-sharded
     (column-parallel, no collective) feeding the down projection 28672 -> 8192 K-sharded (row-parallel, ONE
     all-reduce of M*8192*2 B over RCCL/xGMI) - flute_amd/tp.py, reference contract vllm_utils.py:224-226,
@@ -232,7 +232,7 @@ def tp_mlp_pair(world, rank, device, dist, pairs=50):
             dist.barrier(device_ids=[device.index])
 
     def run(collective):
-        body(collective, 5)
+        body(collective, max(1, warmup))
         sync()
         mode = "hipGraph"
         try:
@@ -242,12 +242,11 @@ def tp_mlp_pair(world, rank, device, dist, pairs=50):
             graph.replay()
             sync()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best = 1e9
-            for _ in range(3):
-                s.record(); graph.replay(); e.record()
-                torch.cuda.synchronize()
-                best = min(best, s.elapsed_time(e) / pairs * 1e3)
-                sync()
+            # ONE timed replay of exactly `pairs` steps, bracketed by barrier + synchronize on both sides
+            s.record(); graph.replay(); e.record()
+            torch.cuda.synchronize()
+            best = s.elapsed_time(e) / pairs * 1e3
+            sync()
         except Exception:                                   # noqa: BLE001 - capture of the collective unsupported
             torch.cuda.synchronize()
             mode = "eager"
@@ -296,7 +295,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # FLUTE_BENCH_FORCE_DIST=1: take the process-group path on one GPU too (exercises the TP leg under torchrun)
+    saved_stdout = None
     if world > 1 or os.environ.get("FLUTE_BENCH_FORCE_DIST") == "1":
+        # RCCL prints a version banner on STDOUT when a communicator is created: route fd 1 to stderr until the one
+        # JSON line is due, so that stdout carries that line and nothing else
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
@@ -334,7 +339,8 @@ def main():
     # Llama-3-70B MLP pair (configs[3]): with a process group it is the headline (strong scaling, one RCCL
     # all-reduce inside the captured graph); on one GPU it is an extra (TP = 1, no collective)
     try:
-        tp_pair = tp_mlp_pair(world, rank, device, dist) if (dist is not None or not args.no_extras) else None
+        tp_pair = (tp_mlp_pair(world, rank, device, dist, pairs=max(1, min(args.steps, 500)), warmup=min(args.warmup, 20))
+                   if (dist is not None or not args.no_extras) else None)
     except Exception as exc:          # never lose the line to this leg  # noqa: BLE001
         tp_pair = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
@@ -474,13 +480,13 @@ def main():
                 "metric": "qgemm effective GB/s, M=1, W4G64 fp16, Llama-3-70B MLP pair 8192x28672 -> 28672x8192, "
                           "tensor-parallel over all GPUs incl. the RCCL all-reduce, HBM-cold",
                 "value": tp_pair["whole_job_GBps_with_allreduce"], "ms_per_step": round(t_us / 1e3, 6),
-                "scaling": "strong", "steps": args.steps,
+                "scaling": "strong", "steps": max(1, min(args.steps, 500)),
                 "config": {"workload": tp_pair["workload"] + " (BASELINE configs[3])",
                            "template_ids": tp_pair["template_ids"], "launch": tp_pair["launch"],
                            "parallelism": f"tp{world}: N-sharded up projection, K-sharded down projection, 1 all-reduce of "
                                           f"{tp_pair['allreduce_bytes']} B per pair",
-                           "step": "one MLP pair (two qgemm launches + one all-reduce); the driver's --steps applies "
-                                   "to the replica leg, the pair is timed over 50 captured pairs x 3 replays"},
+                           "step": "one MLP pair (two qgemm launches + one all-reduce); --steps pairs (at most 500) are "
+                                   "captured in one hipGraph and ONE replay is timed"},
                 "roofline": {"bound": "hbm", "achieved": round(per_gpu / tp_pair["kernels_us"] / 1e3, 2),
                              "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(per_gpu / tp_pair["kernels_us"] / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -492,7 +498,12 @@ def main():
             out["tp_mlp_pair"] = tp_pair
         if dist is None and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, K, bits, g)
-        print(json.dumps(out))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)                      # teardown chatter goes to stderr again
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
