@@ -301,14 +301,16 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     //   256-row block fp16 109 / 129, bf16 125 / 136;  128-row block fp16 74 / 81, bf16 80 / 88;
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
-    if (bits == 4 && (K >> lg) % 8 == 0 && units % 64 == 0 && K % 64 == 0 && (family == 2 || ov.family == kFamilyBlock) &&
-        (ov.family < 0 || ov.family == kFamilyBlock)) {
-        const long tiles256 = (long)ceil_div(M, 256) * (units / 64), tiles128 = (long)ceil_div(M, 128) * (units / 64);
+    const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32)
+    if ((bits == 4 || bits == 2) && (K >> lg) % 8 == 0 && units % blk_units == 0 && K % 64 == 0 &&
+        (family == 2 || ov.family == kFamilyBlock) && (ov.family < 0 || ov.family == kFamilyBlock)) {
+        const long tiles256 = (long)ceil_div(M, 256) * (units / blk_units), tiles128 = (long)ceil_div(M, 128) * (units / blk_units);
         if (ov.family == kFamilyBlock) {
             blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
             // slabs_per_wave: 1 lockstep / 2 software-pipelined schedule of the 2 x 4 split; 3 or automatic: 1 x 8 split
             if (ov.slabs == 2) blk_cfg |= 2;
             else if (ov.slabs != 1) blk_cfg += 4;
+            if (bits == 2) blk_cfg = 4 + (blk_cfg & 1);      // the 2 x 4 split (either schedule) exists for 4-bit layers only
         } else if (M >= 256) {
             const bool bf = dtype == FLUTE_BF16;
             auto block_us = [&](long tiles, double alone, double busy) {
@@ -337,7 +339,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
         const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;      // block rows / 32
-        const int tiles_m = ceil_div(M, bm), tiles_n = units / 64;
+        const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
         int splitk = (ov.splitk > 0) ? ov.splitk : 1;
         const int align_k = std::max(64, 8 << lg);
         int kps = round_up(ceil_div(K, splitk), align_k);
@@ -352,7 +354,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         p->splitk = splitk; p->k_per_split = kps;
         p->grid = (unsigned)((long)tiles_m * tiles_n * splitk);
         p->block = 512;
-        p->lds_bytes = (size_t)block_lds_bytes(bits, tm, 2, 4);
+        // pair table + three activation stages + per wave: two scale blocks and a sink
+        p->lds_bytes = (size_t)((128 << (2 * bits)) + 3 * (bm / 16) * 2 * 1024 + 8 * 3 * 1024);
         p->lut_copies = 32;
     } else {
         // M > decode range: MFMA kernel (qgemm_tile.h).  MT 16-row tiles per wave (1 for M <= 16),
@@ -647,12 +650,12 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.partial = reinterpret_cast<float*>(workspace);
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
         const int bm = p.m_tiles * 32;
-        b.tiles_m = ceil_div(M, bm); b.tiles_n = (N / 4) / 64;
+        b.tiles_m = ceil_div(M, bm); b.tiles_n = N / 256;
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
         // XCD x (block id % 8) owns a contiguous range of row blocks (their activations then stay in its L2
         // while the weights stream through), else of column blocks
         b.order = (b.tiles_m % 8 == 0) ? 1 : ((b.tiles_n % 8 == 0) ? 2 : 0);
-        BlockKernel fn = block_kernel_b4(dtype, t.tile_p, p.m_block);
+        BlockKernel fn = (num_bits == 2) ? block_kernel_b2(dtype, t.tile_p, p.m_block) : block_kernel_b4(dtype, t.tile_p, p.m_block);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&b};

@@ -20,10 +20,16 @@ namespace flute_amd {
 
 // RT = 16: 256-row blocks as described; RT = 8 / 4: 128- / 64-row blocks (every fragment lives in a slot, each replaced
 // by the NEXT half step's fragment of the same row tile; smaller stages, for outputs with too few 256-row blocks).
-template <typename T, int TILEP, int RT = 16>
+// BITS = 2: a word holds 8 four-bit pair fields, so the wave's 32 columns are 4 units x 8 fields (lane r16: unit r16 % 4,
+// field r16 / 4, + 4 for the second column tile) and the pair table has 16 entries; everything else is the same code.
+template <typename T, int TILEP, int RT = 16, int BITS = 4>
 __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args) {
     using NT = Num<T>;
-    constexpr int BITS = 4;
+    static_assert(BITS == 4 || BITS == 2, "3-bit layers use the per-wave MFMA kernel (qgemm_tile.h)");
+    constexpr int J = 16 / BITS;                                   // fields per word
+    constexpr int U = 32 / J;                                      // units per wave (32 columns)
+    constexpr int FPT = 16 / U;                                    // fields per column tile and unit: tile t uses field fsel + FPT t
+    constexpr int FB = 2 * BITS;                                   // bits of a pair index
     // (RT = 4, 64-row blocks, works too but a block then takes 87 % of a 128-row block's time for half its work:
     // the per-step costs - 8 lookups per wave, the DMA queue, two barriers - do not shrink with the rows; not instantiated)
     static_assert(RT == 16 || RT == 8 || RT == 4, "row tiles per block");
@@ -50,8 +56,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const int lane = tid & 63;
     const int r16 = lane & 15;
     const int q4 = lane >> 4;
-    const int u8 = lane & 7;                                       // this lane's unit within the wave's 8
-    const int fsel = (lane >> 3) & 1;                              // ... and field of column tile 0 (tile 1: + 2)
+    const int u8 = r16 % U;                                        // this lane's unit within the wave's U
+    const int fsel = r16 / U;                                      // ... and field of column tile 0 (tile 1: + FPT)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int bid = blockIdx.x, split = 0;
@@ -70,14 +76,14 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         tn_idx = bid / a.tiles_m;
     }
     const int m0 = tm_idx * BM;
-    const int unit0 = (tn_idx * NW + wave) * 8;                    // this wave's 8 units
+    const int unit0 = (tn_idx * NW + wave) * U;                    // this wave's U units
     const int kbeg = split * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nsteps = (kend - kbeg) >> 6;
     const uint32_t row_bytes = (uint32_t)a.K * 2u;
 
     const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
-    const srd_t w_srd = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit0 * row_bytes, 8u * row_bytes);
+    const srd_t w_srd = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit0 * row_bytes, (uint32_t)U * row_bytes);
     const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
     // Activations: this wave's PPW pieces are consecutive row tiles of one half (piece p = wave * PPW + i).  Rows
     // past M need no flag: their byte offset is past the descriptor's range (voffset is what the range check
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const uint32_t x_dv = 16u * row_bytes;                         // next row tile
     const uint32_t x_lds0 = (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u;
     const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)q4 * 16u;
-    // scale block: lane L < 32 fetches 8 groups of column (unit L % 8, field L / 8); the image is lane-linear
+    // scale block: lane L < 32 fetches 8 groups of column (unit L % U, field L / U); the image is lane-linear
     const uint32_t s_voff = (lane < 32)
-        ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 7)) + (lane >> 3) * TILEP) * a.G) * 2) : 0x80000000u;
+        ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane % U)) + (lane / U) * TILEP) * a.G) * 2) : 0x80000000u;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
 
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
     const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(r16 * 4 + (q4 ^ blk_swz(r16))) * 16u;
     const uint32_t frag_hi = frag_lo + 65536u;
-    const uint32_t sc_lane = sc_base + (uint32_t)(fsel * 8 + u8) * 16u;
-    const uint32_t shift0 = (uint32_t)fsel * 8u;                   // bit offset of this lane's field, column tile 0
+    const uint32_t sc_lane = sc_base + (uint32_t)(fsel * U + u8) * 16u;
+    const uint32_t shift0 = (uint32_t)(fsel * FB);                 // bit offset of this lane's field, column tile 0
 
     f32x4_t acc[RT][NT2];
 #pragma unroll
@@ -144,11 +150,11 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         uint32_t& d0 = scn[0];
         uint32_t& d1 = scn[1];
         asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
-        asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");     // field + 2 = 16 lanes on
+        asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");     // field + FPT = 16 image lanes on
     };
     auto lookup = [&](const u32x4_t& qw, auto n_tag) {
         constexpr int n = decltype(n_tag)::value;                  // tile n / 4, word n % 4
-        const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(16 * (n >> 2)), 8u);
+        const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(FB * FPT * (n >> 2)), (uint32_t)FB);
         v[n] = lds_lookup32((idx << 7) | lane_off);
     };
     auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
@@ -258,14 +264,14 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
 
     // ---- epilogue: accumulator register i of lane (r16, q4) = weight row 4 q4 + i of the column tile = unit
     // (4 q4 + i) % 8, field q4 / 2 + 2 t: four consecutive columns; the lane's output row is r16 ----
-    const int c_unit = unit0 + (q4 & 1) * 4;
+    const int c_unit = unit0 + (4 * q4) % U;
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int row = m0 + r * 16 + r16;
         if (row < a.M) {
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
-                const int col = unit_col0<BITS, TILEP>(c_unit) + ((q4 >> 1) + 2 * t) * TILEP;
+                const int col = unit_col0<BITS, TILEP>(c_unit) + ((4 * q4) / U + FPT * t) * TILEP;
                 const f32x4_t o4 = acc[r][t];
                 if (a.splitk == 1) {
                     uint2 o;

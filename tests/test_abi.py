@@ -87,6 +87,8 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 256      # 128-row blocks: one per CU
     rc, p = plan(1024, 4096, 4096)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel is faster
+    rc, p = plan(4096, 4096, 4096, bits=2, tid=0)
+    assert rc == 0 and p.family == 3 and p.m_block == 4 and p.lds_bytes <= 160 * 1024      # 2-bit layers too
     rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # 3-bit layers stay on the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches

@@ -30,13 +30,14 @@ def emit(r):
 
 def check():
     nfail = 0
-    for (tile_p, g, dtype, K, N) in [(32, 64, f16, 4096, 4096), (64, 64, bf16, 2048, 1024), (32, 128, f16, 3072, 512),
-                                     (32, 32, f16, 1024, 256), (64, 256, bf16, 4096, 256), (32, 64, f16, 4096, 11008)]:
-        bits = 4
+    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
+                                           (4, 32, 32, f16, 1024, 256), (4, 64, 256, bf16, 4096, 256), (4, 32, 64, f16, 4096, 11008),
+                                           (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (2, 32, 32, bf16, 1024, 256),
+                                           (2, 64, 256, f16, 3072, 512)]:
         torch.manual_seed(K + N)
-        W = torch.randint(0, 16, (K, N), dtype=torch.uint8, device=d)
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
         S = torch.randn(N, K // g, device=d).to(dtype)
-        table = torch.randn(16, device=d).to(dtype)
+        table = torch.randn(2 ** bits, device=d).to(dtype)
         table2 = utils.make_qmap2_from_qmap(table)
         tid = tid_of(bits, tile_p)
         Q = utils.pack(W, bits, [tid], num_sms)
@@ -53,7 +54,7 @@ def check():
                         dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=2), dict(family=3, m_tiles=8, slabs_per_wave=3),
                         dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3),
                         dict(family=3, m_tiles=4, splitk=2, slabs_per_wave=3)):
-                rec = {"kind": "check", "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "shape": shp}
+                rec = {"kind": "check", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "shape": shp}
                 try:
                     ovr = dev.Overrides(**shp)
                     pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
@@ -124,7 +125,32 @@ def timing():
             torch.cuda.empty_cache()
 
 
+def timing_b2():
+    for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (4096, 11008, 4096), (1024, 11008, 4096)):
+        for dtype in (f16, bf16):
+            for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict()):
+                lay = bench.Layer(M, N, K, 2, 64, dtype, d, bench.copies_for(N, K, 2))
+                lay.template_id = tid_of(2, 32)
+                if shp.get("family") == 2:
+                    lay.tune()
+                lay.ovr = dev.Overrides(**shp)
+                rec = {"kind": "time", "bits": 2, "M": M, "N": N, "K": K, "dtype": str(dtype)[6:], "shape": shp}
+                try:
+                    pl = dev.get_plan(M, N, K, 2, 64, lay.template_id, num_sms, dtype, lay.ovr)
+                    rec["plan"] = {k: pl[k] for k in ("family", "m_block", "m_tiles", "waves", "kw", "splitk", "grid")}
+                    ms = min(bench.time_graph(lay, 100, 5, torch.cuda.synchronize)[0] for _ in range(2))
+                    us = ms * 10
+                    rec.update(us=round(us, 2), TFLOPs=round(lay.flops() / us / 1e6, 1))
+                except Exception as ex:  # noqa: BLE001
+                    rec["error"] = str(ex)[:200]
+                emit(rec)
+                del lay
+                torch.cuda.empty_cache()
+
+
 rc = 0
+if "time_b2" in what:
+    timing_b2()
 if "check" in what:
     rc = check()
 if "time" in what:
