@@ -298,7 +298,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
-    //   256-row block fp16 109 / 129, bf16 125 / 136;  128-row block fp16 74 / 81, bf16 80 / 88;
+    //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
     const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32)
@@ -318,8 +318,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 const double last = rest == 0 ? 0.0 : (rest * 4 >= (long)num_sms * 3 ? busy : alone);
                 return ((double)whole * busy + last) * (double)K / 4096.0 + 3.0;
             };
-            const double t256 = block_us(tiles256, bf ? 125.0 : 109.0, bf ? 136.0 : 129.0);
-            const double t128 = block_us(tiles128, bf ? 80.0 : 74.0, bf ? 88.0 : 81.0);
+            const double t256 = block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
+            const double t128 = block_us(tiles128, bf ? 80.0 : 72.0, bf ? 89.0 : 81.0);
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
             int dbl = 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;

@@ -33,6 +33,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     // (RT = 4, 64-row blocks, works too but a block then takes 87 % of a 128-row block's time for half its work:
     // the per-step costs - 8 lookups per wave, the DMA queue, two barriers - do not shrink with the rows; not instantiated)
     static_assert(RT == 16 || RT == 8 || RT == 4, "row tiles per block");
+    constexpr bool SPLIT = __is_same(T, BF16) && RT == 16;         // batch issue spread over both half steps (below)
+    static_assert(RT * 2 / 8 + 3 <= RT, "the batch (PPW + 3 requests) is issued over the row tiles of a half step");
     constexpr int NS = RT < 8 ? RT : 8;                            // fragment slots
     constexpr int NW = 8, BM = RT * 16, NT2 = 2;                   // waves, rows, column tiles per wave
     constexpr int PIECES = RT * 2, PPW = PIECES / NW;
@@ -119,6 +121,24 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
                   blk_start ? sc_base + (uint32_t)((g >> 3) & 1) * 1024u : sc_sink);
     };
 
+    // the same batch, one request at a time (in the loop the BATCH requests ride between the MFMAs of the first row
+    // tiles of half step 0 instead of queueing behind barrier (A) in all eight waves at once); same order as above
+    auto issue_one = [&](auto slot_tag, auto i_tag, int u) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int i = decltype(i_tag)::value;
+        const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
+        if constexpr (i < PH) {
+            dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+        } else if constexpr (i < PH + 2) {
+            w[slot][i - PH] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)(i - PH) * 64u);
+        } else {
+            const int g = (int)(k0 >> a.lg);
+            const bool blk_start = (u < nsteps) && ((g & 7) == 0 || u == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
+            dma16_buf(s_voff, s_srd, (uint32_t)((g >> 3) * 16),
+                      blk_start ? sc_base + (uint32_t)((g >> 3) & 1) * 1024u : sc_sink);
+        }
+    };
+
     issue_batch(std::integral_constant<int, 0>{}, 0);
     issue_batch(std::integral_constant<int, 1>{}, 1);
     {
@@ -186,11 +206,11 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         constexpr int nh = h ^ 1;
         wait_lds();
         if constexpr (h == 0) {
-            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free
-            issue_batch(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, t + 2);
+            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free: batch t+2 follows, spread over the rows
         } else {
-            // (B) batch t+1 has landed once at most batch t+2 is outstanding
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
+            // (B) batch t+1 has landed once at most batch t+2 is outstanding (SPLIT: only its PH activation pieces have
+            // been issued by now; its weight / scale requests follow during this half step)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(SPLIT ? PH : BATCH) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         u32x4_t bf[NT2];
@@ -213,6 +233,20 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
             }
 #pragma unroll
             for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R & 7], acc[R][c]);
+            // batch t+2 rides between the MFMAs, one request per row tile (eight waves issuing a whole batch at once
+            // behind barrier (A) queue on the texture path and stall in order: 108.7 -> 99.9 us per 256-row block).
+            // SPLIT (bf16 256-row blocks, whose multiply stage is 3x longer): the PH activation pieces on every
+            // second row tile of half step 0, the weight pieces and the scale block in half step 1 (116 -> 104 us;
+            // fp16 and the 128-row blocks measured slower that way)
+            if constexpr (SPLIT) {
+                if constexpr (h == 0 && (R & 1) == 0 && R / 2 < PH)
+                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, R / 2>{}, t + 2);
+                if constexpr (h == 1 && (R & 1) == 0 && R / 2 < 3)
+                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, PH + R / 2>{}, t + 2);
+            } else {
+                if constexpr (h == 0 && R < BATCH)
+                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, r_tag, t + 2);
+            }
             if constexpr (RT == 16 && R < 8) {
                 frag(slot_tag, h_tag, std::integral_constant<int, R + 8>{});
             } else {
