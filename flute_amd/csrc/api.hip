@@ -301,8 +301,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
-    const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32)
-    if ((bits == 4 || bits == 2) && (K >> lg) % 8 == 0 && units % blk_units == 0 && K % 64 == 0 &&
+    const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32, 3-bit: 16)
+    const bool b3_ok = bits != 3 || (size_t)3 * (N >> 4) * K * 2 < (size_t)0xfffffff0u;   // one descriptor over Q
+    if (b3_ok && (K >> lg) % 8 == 0 && units % blk_units == 0 && K % 64 == 0 &&
         (family == 2 || ov.family == kFamilyBlock) && (ov.family < 0 || ov.family == kFamilyBlock)) {
         const long tiles256 = (long)ceil_div(M, 256) * (units / blk_units), tiles128 = (long)ceil_div(M, 128) * (units / blk_units);
         if (ov.family == kFamilyBlock) {
@@ -311,6 +312,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (ov.slabs == 2) blk_cfg |= 2;
             else if (ov.slabs != 1) blk_cfg += 4;
             if (bits == 2) blk_cfg = 4 + (blk_cfg & 1);      // the 2 x 4 split (either schedule) exists for 4-bit layers only
+            if (bits == 3) blk_cfg = 5;                      // 3-bit layers: 128-row blocks of qgemm_block3.h only
         } else if (M >= 256) {
             const bool bf = dtype == FLUTE_BF16;
             auto block_us = [&](long tiles, double alone, double busy) {
@@ -318,12 +320,16 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 const double last = rest == 0 ? 0.0 : (rest * 4 >= (long)num_sms * 3 ? busy : alone);
                 return ((double)whole * busy + last) * (double)K / 4096.0 + 3.0;
             };
-            const double t256 = block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
-            const double t128 = block_us(tiles128, bf ? 80.0 : 72.0, bf ? 89.0 : 81.0);
+            // 3-bit layers (qgemm_block3.h): 128-row blocks only (78 / 85 us alone, 85 / 90 busy); the per-wave kernel
+            // runs them at 330-380 TFLOP/s
+            const double t256 = (bits == 3) ? 1e30 : block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
+            const double t128 = (bits == 3) ? block_us(tiles128, bf ? 85.0 : 78.0, bf ? 90.0 : 85.0)
+                                            : block_us(tiles128, bf ? 80.0 : 72.0, bf ? 89.0 : 81.0);
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
             int dbl = 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;
-            const double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            const double wave_tf = (bits == 3) ? (bf ? 355.0 : 370.0)
+                                   : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl));
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
             else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
@@ -655,7 +661,8 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         // XCD x (block id % 8) owns a contiguous range of row blocks (their activations then stay in its L2
         // while the weights stream through), else of column blocks
         b.order = (b.tiles_m % 8 == 0) ? 1 : ((b.tiles_n % 8 == 0) ? 2 : 0);
-        BlockKernel fn = (num_bits == 2) ? block_kernel_b2(dtype, t.tile_p, p.m_block) : block_kernel_b4(dtype, t.tile_p, p.m_block);
+        BlockKernel fn = (num_bits == 2) ? block_kernel_b2(dtype, t.tile_p, p.m_block)
+                         : (num_bits == 3) ? block_kernel_b3(dtype, t.tile_p, p.m_block) : block_kernel_b4(dtype, t.tile_p, p.m_block);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&b};

@@ -1,0 +1,11 @@
+// Explicit instantiations of the block-tiled prefill kernel for num_bits = 3 (qgemm_block3.h; TileP = 32 only,
+// like every 3-bit template).
+#include "kernels.h"
+#include "qgemm_block3.h"
+namespace flute_amd {
+// cfg 5: 128 x 256 blocks (the only geometry: the weight ring leaves no registers for 256-row blocks)
+BlockKernel block_kernel_b3(int dtype, int tile_p, int cfg) {
+    if (tile_p == 32 && cfg == 5) return dtype == 0 ? (BlockKernel)qgemm_block3_kernel<F16, 8> : (BlockKernel)qgemm_block3_kernel<BF16, 8>;
+    return nullptr;
+}
+}  // namespace flute_amd

@@ -1,0 +1,305 @@
+// Prefill kernel for 3-bit layers: the 1 x 8 block geometry of qgemm_block2.h on the three-plane layout.
+//
+// A 3-bit unit is 16 columns (column = unit_col0 + 32 j, j = 0..15) whose pair indices live in three bit planes:
+// field j < 15 sits in plane j % 3 at bit 6 (j / 3); field 15 takes the top two bits of all three planes
+// (common.h `field<3>`).  Giving a wave "its" columns as units x fields the 4-bit way would make the plane and the
+// shift lane-dependent (and field 15 a 5-instruction special case in every lane).  Instead the MFMA weight row is
+// the UNIT: a workgroup owns 16 units x 16 fields = 256 columns, lane (r16, q4) holds words 4 q4 .. 4 q4 + 3 of
+// unit r16, and every wave multiplies two column tiles = two FIELDS of those 16 units.  Plane and shift are then
+// wave-uniform scalars (one v_bfe_u32 per lookup, as for 4 bits) and the accumulator of lane (r16, q4) holds four
+// consecutive units = four consecutive columns (8-B stores).  The fields are dealt to the waves so that a wave's
+// two fields share a plane wherever possible - (0,3) (6,9) (1,4) (7,10) (2,5) (8,11): ONE 16-B piece per lane and
+// half step feeds both tiles, as for 4 bits - wave 6 takes (12,13) (two planes) and wave 7 takes (14,15): field 15
+// needs all three planes (5 VALU per lookup), one of which is field 14's.  Three instantiations of the body, chosen
+// by a wave-uniform branch; all execute the same barriers.
+// Everything else is qgemm_block2.h with RT = 8 (128-row blocks: wave 7's ring of three plane pieces per half step
+// leaves no registers for 16 row tiles, and every wave of a kernel gets the same allocation):
+// stages, fragment slots, two barriers per step, requests riding between the MFMAs, exact step count.
+// Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation, one rounding of the output.
+// The per-wave MFMA kernel (qgemm_tile.h) ran these layers at 360-380 TFLOP/s (M = 4096).
+#pragma once
+#include "qgemm_block2.h"
+
+namespace flute_amd {
+
+template <typename T, int RT>
+__global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args) {
+    using NT = Num<T>;
+    constexpr int BITS = 3, TILEP = 32;
+    static_assert(RT == 8, "128-row blocks (the weight ring leaves no registers for 16 row tiles)");
+    constexpr int NW = 8, BM = RT * 16, NT2 = 2;
+    constexpr int PIECES = RT * 2, PPW = PIECES / NW, PH = PPW;
+    constexpr int LUT_BYTES = 64 * 128;
+    constexpr int STAGE_BYTES = PIECES * 1024;
+
+    BlockArgs a = args;
+    {
+#define FLUTE_OPAQUE(x) asm volatile("" : "+s"(x))
+        FLUTE_OPAQUE(a.A); FLUTE_OPAQUE(a.Q); FLUTE_OPAQUE(a.D); FLUTE_OPAQUE(a.S); FLUTE_OPAQUE(a.QM2);
+        FLUTE_OPAQUE(a.partial); FLUTE_OPAQUE(a.M); FLUTE_OPAQUE(a.N); FLUTE_OPAQUE(a.K); FLUTE_OPAQUE(a.G);
+        FLUTE_OPAQUE(a.lg); FLUTE_OPAQUE(a.tiles_m); FLUTE_OPAQUE(a.tiles_n); FLUTE_OPAQUE(a.splitk);
+        FLUTE_OPAQUE(a.k_per_split); FLUTE_OPAQUE(a.order);
+#undef FLUTE_OPAQUE
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r16 = lane & 15;
+    const int q4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bid = blockIdx.x, split = 0;
+    if (a.splitk > 1) { split = bid % a.splitk; bid /= a.splitk; }
+    int tm_idx, tn_idx;
+    if (a.order == 1) {
+        const int per = a.tiles_m >> 3, x = bid & 7, i = bid >> 3;
+        tm_idx = x * per + i % per;
+        tn_idx = i / per;
+    } else if (a.order == 2) {
+        const int per = a.tiles_n >> 3, x = bid & 7, i = bid >> 3;
+        tn_idx = x * per + i % per;
+        tm_idx = i / per;
+    } else {
+        tm_idx = bid % a.tiles_m;
+        tn_idx = bid / a.tiles_m;
+    }
+    const int m0 = tm_idx * BM;
+    const int unit0 = tn_idx * 16;                                 // the workgroup's 16 units (lane r16 <-> unit)
+    const int kbeg = split * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nsteps = (kend - kbeg) >> 6;
+    const uint32_t row_bytes = (uint32_t)a.K * 2u;
+
+    const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
+    const srd_t w_srd = make_srd(a.Q, (uint32_t)min((size_t)(3 * (a.N >> 4)) * row_bytes, (size_t)0xfffffff0u));
+    const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
+    const int p0 = wave * PPW;
+    const uint32_t x_v0 = (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
+                                      ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2);
+    const uint32_t x_dv = 16u * row_bytes;
+    const uint32_t x_lds0 = (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u;
+    // plane rows of this lane's unit (common.h unit_row<3>): plane 0 = row u, planes 1 / 2 = 32 rows apart
+    const int u = unit0 + r16;
+    const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
+    const uint32_t wv_p1 = (uint32_t)((a.N >> 4) + (u >> 5) * 64 + (u & 31)) * row_bytes + (uint32_t)q4 * 16u;
+    const uint32_t wv_dp = 32u * row_bytes;
+    const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
+    const uint32_t sc_sink = sc_base + 2048u;
+
+    {   // pair table: 64 entries, 32 copies each (128-B stride)
+        for (int p = tid; p < 64 * 8; p += NW * 64) {
+            const uint32_t v = a.QM2[p >> 3];
+            *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(v, v, v, v);
+        }
+    }
+    const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
+    const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(r16 * 4 + (q4 ^ blk_swz(r16))) * 16u;
+    const uint32_t sc_lane = sc_base + (uint32_t)r16 * 16u;
+
+    // ---- the body: three instantiations (see the header), the same barriers in each ----
+    auto body = [&](auto kind_tag) {
+        // KIND 0: both fields in one plane (one piece per half step); 1: two planes; 2: fields 14 and 15 (three planes)
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool LAST = KIND == 2;
+        constexpr int NPL = KIND + 1;                              // weight pieces per half step
+        constexpr int BATCH = PH + 2 * NPL + 1;
+        constexpr int NA = BATCH < RT ? BATCH : RT;                // requests issued during half step 0 (one per row tile)
+        constexpr int NB = BATCH - NA;                             // ... during half step 1
+        static_assert(NB <= RT, "batch too long");
+        // tile t = field f_t: plane, bit offset (wave-uniform), this lane's row offset of that plane
+        const int f0 = (wave < 6) ? (wave >> 1) + 6 * (wave & 1) : 2 * wave;          // 0 6 1 7 2 8 | 12 | 14
+        const int f1 = (wave < 6) ? f0 + 3 : f0 + 1;                                   // 3 9 4 10 5 11 | 13 | 15
+        const uint32_t sh0 = (uint32_t)(6 * (f0 / 3)), sh1 = (uint32_t)(6 * (f1 / 3));
+        const int pl0 = f0 % 3, pl1 = f1 % 3;
+        const uint32_t wv0 = (pl0 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl0 - 1) * wv_dp;
+        const uint32_t wv1 = (pl1 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl1 - 1) * wv_dp;
+        // scale block: lane L < 32 fetches 8 groups of column (unit L % 16, field f_(L / 16)); lane-linear image
+        const uint32_t s_voff = (lane < 32)
+            ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 15)) + ((lane >> 4) ? f1 : f0) * TILEP) * a.G) * 2) : 0x80000000u;
+
+        u32x4_t w[BLK_STAGES][2][NPL];
+        auto issue_one = [&](auto slot_tag, auto i_tag, int ustep) {
+            constexpr int slot = decltype(slot_tag)::value;
+            constexpr int i = decltype(i_tag)::value;
+            const uint32_t k0 = (uint32_t)(kbeg + min(ustep, nsteps - 1) * 64);
+            if constexpr (i < PH) {
+                dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+            } else if constexpr (i < PH + 2 * NPL) {
+                constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;
+                uint32_t vo;
+                if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
+                else vo = (c == 0) ? wv0 : wv1;
+                w[slot][h][c] = buf_load16(vo, w_srd, k0 * 2u + (uint32_t)h * 64u);
+            } else {
+                const int g = (int)(k0 >> a.lg);
+                const bool blk_start = (ustep < nsteps) && ((g & 7) == 0 || ustep == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
+                dma16_buf(s_voff, s_srd, (uint32_t)((g >> 3) * 16),
+                          blk_start ? sc_base + (uint32_t)((g >> 3) & 1) * 1024u : sc_sink);
+            }
+        };
+        auto issue_batch = [&](auto slot_tag, int ustep) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (issue_one(slot_tag, std::integral_constant<int, I>{}, ustep), ...);
+            }(std::make_integer_sequence<int, BATCH>{});
+        };
+        auto wait_batch = [&](auto slot_tag, auto n_tag) {         // releases ring slot `slot` once <= n requests are outstanding
+            constexpr int n = decltype(n_tag)::value;
+            auto& ws = w[decltype(slot_tag)::value];               // (named first: clang does not capture through asm operands)
+            if constexpr (NPL == 3)
+                asm volatile("s_waitcnt vmcnt(%6)"
+                             : "+v"(ws[0][0]), "+v"(ws[0][1]), "+v"(ws[0][2]), "+v"(ws[1][0]), "+v"(ws[1][1]), "+v"(ws[1][2])
+                             : "n"(n) : "memory");
+            else if constexpr (NPL == 2)
+                asm volatile("s_waitcnt vmcnt(%4)"
+                             : "+v"(ws[0][0]), "+v"(ws[0][1]), "+v"(ws[1][0]), "+v"(ws[1][1])
+                             : "n"(n) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ws[0][0]), "+v"(ws[1][0]) : "n"(n) : "memory");
+        };
+
+        issue_batch(std::integral_constant<int, 0>{}, 0);
+        issue_batch(std::integral_constant<int, 1>{}, 1);
+
+        f32x4_t acc[RT][NT2];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint32_t v[8];                                             // hidden lookups of the NEXT half step: [tile][word]
+        u32x4_t af[8];                                             // fragment slots = the 8 row tiles
+        uint32_t scn[NT2];
+
+        auto scales = [&](int t, int h) {
+            const int grp = (kbeg + t * 64 + h * 32) >> a.lg;
+            const uint32_t sb = sc_lane + (uint32_t)((grp >> 3) & 1) * 1024u + (uint32_t)(grp & 7) * 2u;
+            uint32_t& d0 = scn[0];
+            uint32_t& d1 = scn[1];
+            asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
+            asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");
+        };
+        auto lookup = [&](const u32x4_t (&qw)[NPL], auto n_tag) {
+            constexpr int n = decltype(n_tag)::value;              // tile n / 4, word n % 4
+            constexpr int ww = n & 3;
+            uint32_t idx;
+            if constexpr (LAST) {
+                if constexpr (n < 4) idx = __builtin_amdgcn_ubfe(qw[2][ww], 24u, 6u);              // field 14: plane 2, bit 24
+                else idx = (qw[0][ww] >> 30) | ((qw[1][ww] >> 28) & 0xcu) | ((qw[2][ww] >> 26) & 0x30u);   // field 15 (common.h field<3>)
+            } else if constexpr (n < 4) {
+                idx = __builtin_amdgcn_ubfe(qw[0][ww], sh0, 6u);
+            } else {
+                idx = __builtin_amdgcn_ubfe(qw[KIND == 0 ? 0 : 1][ww], sh1, 6u);
+            }
+            v[n] = lds_lookup32((idx << 7) | lane_off);
+        };
+        auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+            constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + R) * 1024;
+            static_assert(off < 65536, "one address register covers the three stages");
+            u32x4_t& dst = af[R];
+            const uint32_t addr = frag_lo;                         // (named first: clang does not capture through asm operands)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+        };
+        auto wait_lds = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                           "+v"(scn[0]), "+v"(scn[1])
+                         : : "memory");
+        };
+
+        auto half = [&](auto slot_tag, auto h_tag, int t) {
+            constexpr int slot = decltype(slot_tag)::value;
+            constexpr int h = decltype(h_tag)::value;
+            constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;
+            constexpr int nh = h ^ 1;
+            wait_lds();
+            if constexpr (h == 0) {
+                __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free: batch t+2 follows, spread over the rows
+            } else {
+                // (B) batch t+1 has landed once at most the NA requests of batch t+2 issued so far are outstanding
+                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, NA>{});
+                __builtin_amdgcn_s_barrier();
+            }
+            u32x4_t bf[NT2];
+#pragma unroll
+            for (int c = 0; c < NT2; ++c)
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], scn[c]);
+            scales(t + h, nh);
+            const u32x4_t (&qw)[NPL] = w[nslot][nh];
+            auto row = [&](auto r_tag) {
+                constexpr int R = decltype(r_tag)::value;
+#pragma unroll
+                for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
+                if constexpr (h == 0 && R < NA)
+                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, r_tag, t + 2);
+                if constexpr (h == 1 && R < NB)
+                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, NA + R>{}, t + 2);
+                frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
+                lookup(qw, r_tag);
+            };
+            [&]<int... R>(std::integer_sequence<int, R...>) {
+                (row(std::integral_constant<int, R>{}), ...);
+            }(std::make_integer_sequence<int, RT>{});
+        };
+
+        // batch 0 and the pair table before anyone reads them
+        wait_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, BATCH>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        scales(0, 0);
+        {
+            const u32x4_t (&qw)[NPL] = w[0][0];
+            [&]<int... R>(std::integer_sequence<int, R...>) {
+                (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
+                (lookup(qw, std::integral_constant<int, R>{}), ...);
+            }(std::make_integer_sequence<int, 8>{});
+        }
+        auto step = [&](auto slot_tag, int t) {
+            half(slot_tag, std::integral_constant<int, 0>{}, t);
+            half(slot_tag, std::integral_constant<int, 1>{}, t);
+        };
+        for (int t0 = 0;; t0 += BLK_STAGES) {                      // unrolled by the ring, left after the LAST step
+            step(std::integral_constant<int, 0>{}, t0);
+            if (t0 + 1 >= nsteps) break;
+            step(std::integral_constant<int, 1>{}, t0 + 1);
+            if (t0 + 2 >= nsteps) break;
+            step(std::integral_constant<int, 2>{}, t0 + 2);
+            if (t0 + 3 >= nsteps) break;
+        }
+        wait_lds();                                                // the prefetch past the end
+        wait_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        wait_batch(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        wait_batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+
+        // ---- epilogue: accumulator register i of lane (r16, q4) = unit 4 q4 + i of the workgroup, i.e. four
+        // consecutive columns of field f_t; the lane's output row is r16 ----
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int orow = m0 + r * 16 + r16;
+            if (orow < a.M) {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) {
+                    const int col = unit_col0<BITS, TILEP>(unit0 + 4 * q4) + (t ? f1 : f0) * TILEP;
+                    const f32x4_t o4 = acc[r][t];
+                    if (a.splitk == 1) {
+                        uint2 o;
+                        o.x = (uint32_t)NT::from_float(o4[0]) | ((uint32_t)NT::from_float(o4[1]) << 16);
+                        o.y = (uint32_t)NT::from_float(o4[2]) | ((uint32_t)NT::from_float(o4[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)orow * a.N + col) = o;
+                    } else {
+                        *reinterpret_cast<f32x4_t*>(a.partial + ((size_t)split * a.M + orow) * a.N + col) = o4;
+                    }
+                }
+            }
+        }
+    };
+
+    if (wave < 6) body(std::integral_constant<int, 0>{});
+    else if (wave == 6) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
+}
+
+}  // namespace flute_amd

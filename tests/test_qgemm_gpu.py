@@ -298,7 +298,7 @@ def test_mfma_scale_block_and_ring_paths(env):
 
 
 def test_block_prefill_kernel(env):
-    """The block-tiled prefill kernels (family 3, qgemm_block2.h / qgemm_block.h; 4- and 2-bit layers): 256- and 128-row blocks, ragged M (rows past M
+    """The block-tiled prefill kernels (family 3, qgemm_block2.h / qgemm_block3.h / qgemm_block.h): 256- and 128-row blocks, ragged M (rows past M
     read as zero and are not stored), every group size (scale blocks of 8 groups arrive by LDS-DMA), both TileP
     layouts and dtypes, a forced grid-level K split; one-hot rows bit-exact (w^ = round_T(lut * s))."""
     from flute_amd import dev
@@ -307,7 +307,9 @@ def test_block_prefill_kernel(env):
                                            (4, 32, 128, torch.float16, 3072, 512), (4, 32, 32, torch.bfloat16, 1024, 256),
                                            (4, 64, 256, torch.float16, 4096, 256),
                                            (2, 32, 64, torch.float16, 2048, 1024), (2, 64, 128, torch.bfloat16, 3072, 512),
-                                           (2, 32, 32, torch.bfloat16, 1024, 256)]:
+                                           (2, 32, 32, torch.bfloat16, 1024, 256),
+                                           (3, 32, 64, torch.float16, 2048, 1024), (3, 32, 128, torch.bfloat16, 3072, 512),
+                                           (3, 32, 32, torch.bfloat16, 1024, 512)]:
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K + N)
         What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
         tid = template_ids_for(env.fa, bits, tile_p)[0]
@@ -340,7 +342,8 @@ def test_block_prefill_kernel(env):
     assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2
     p = dev.get_plan(4096, 4096, 4096, 2, 64, 0, 256, torch.float16)
     assert p["family"] == 3 and p["m_block"] == 4, p                                 # 2-bit layers: the 1 x 8 split only
-    assert dev.get_plan(4096, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)["family"] == 2    # 3 bits: per-wave kernel
+    p = dev.get_plan(4096, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)
+    assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 512, p          # 3 bits: 128-row blocks (qgemm_block3.h)
 
 
 # ---------------------------------------------------------------------------

@@ -33,7 +33,9 @@ def check():
     for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
                                            (4, 32, 32, f16, 1024, 256), (4, 64, 256, bf16, 4096, 256), (4, 32, 64, f16, 4096, 11008),
                                            (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (2, 32, 32, bf16, 1024, 256),
-                                           (2, 64, 256, f16, 3072, 512)]:
+                                           (2, 64, 256, f16, 3072, 512),
+                                           (3, 32, 64, f16, 4096, 2048), (3, 32, 128, bf16, 2048, 1024), (3, 32, 32, bf16, 1024, 512),
+                                           (3, 32, 256, f16, 3072, 512), (3, 32, 64, bf16, 8192, 512)]:
         torch.manual_seed(K + N)
         W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
         S = torch.randn(N, K // g, device=d).to(dtype)
@@ -125,18 +127,21 @@ def timing():
             torch.cuda.empty_cache()
 
 
-def timing_b2():
-    for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (4096, 11008, 4096), (1024, 11008, 4096)):
+def timing_b2(bits=2):
+    for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (4096, 11008 if bits == 2 else 11264, 4096), (1024, 11008 if bits == 2 else 11264, 4096),
+                      (1024, 4096, 4096), (512, 8192, 8192), (256, 28672, 8192)):
         for dtype in (f16, bf16):
             for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict()):
-                lay = bench.Layer(M, N, K, 2, 64, dtype, d, bench.copies_for(N, K, 2))
-                lay.template_id = tid_of(2, 32)
+                if bits == 3 and shp.get("m_tiles") == 8:
+                    continue
+                lay = bench.Layer(M, N, K, bits, 64, dtype, d, bench.copies_for(N, K, bits))
+                lay.template_id = tid_of(bits, 32)
                 if shp.get("family") == 2:
                     lay.tune()
                 lay.ovr = dev.Overrides(**shp)
-                rec = {"kind": "time", "bits": 2, "M": M, "N": N, "K": K, "dtype": str(dtype)[6:], "shape": shp}
+                rec = {"kind": "time", "bits": bits, "M": M, "N": N, "K": K, "dtype": str(dtype)[6:], "shape": shp}
                 try:
-                    pl = dev.get_plan(M, N, K, 2, 64, lay.template_id, num_sms, dtype, lay.ovr)
+                    pl = dev.get_plan(M, N, K, bits, 64, lay.template_id, num_sms, dtype, lay.ovr)
                     rec["plan"] = {k: pl[k] for k in ("family", "m_block", "m_tiles", "waves", "kw", "splitk", "grid")}
                     ms = min(bench.time_graph(lay, 100, 5, torch.cuda.synchronize)[0] for _ in range(2))
                     us = ms * 10
@@ -151,6 +156,8 @@ def timing_b2():
 rc = 0
 if "time_b2" in what:
     timing_b2()
+if "time_b3" in what:
+    timing_b2(3)
 if "check" in what:
     rc = check()
 if "time" in what:
