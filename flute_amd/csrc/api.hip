@@ -289,8 +289,11 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
 
     memset(p, 0, sizeof(*p));
 
+    // Streaming decode kernel: M <= 2; its four-row variant (2- / 4-bit) only on request (override family 0, which
+    // flute_qgemm_hadamard sets for small layers so that the rotation stays fused): measured at M = 3, 4 the MFMA
+    // kernel is as fast on 4096^2 (7.6 vs 7.75 us) and 15-25 % faster on every larger layer (8192x28672: 38.6 vs 48.9).
     const int dec_max = (bits == 3) ? 2 : 4;
-    int family = (M <= dec_max) ? 0 : 2;
+    int family = (M <= 2 || (M <= dec_max && ov.family == 0)) ? 0 : 2;
     if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
     else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
@@ -578,11 +581,20 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
                           workspace, workspace_bytes, template_id, num_sms, nullptr, stream);
 }
 
+// M = 3, 4 with a Hadamard pre-rotation: the four-row decode kernel keeps the rotation fused (one launch) - worth
+// more than the MFMA kernel's edge on layers up to 32 M weights (4096x3584: 8.7 us fused vs 7.6 + a rotation launch)
+static Ovr hadamard_ovr(Ovr o, int hadamard_size, int bits, int M, int N, int K) {
+    if (hadamard_size > 1 && hadamard_size <= 512 && o.family < 0 && M >= 3 && M <= 4 && bits != 3 &&
+        (size_t)N * K <= ((size_t)32 << 20))
+        o.family = 0;
+    return o;
+}
+
 int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hadamard_size, int M,
                                int N, int K, int template_id, int num_sms, size_t workspace_bytes) {
     flute_plan p;
-    if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes, ovr_of(nullptr),
-                  &p, nullptr, nullptr))
+    if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
+                  hadamard_ovr(ovr_of(nullptr), hadamard_size, num_bits, M, N, K), &p, nullptr, nullptr))
         return 0;
     return hadamard_fusable(p, hadamard_size, K) ? 1 : 0;
 }
@@ -607,8 +619,8 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     flute_template_info t;
     StreamArgs sa;
     if (!workspace) workspace_bytes = 0;
-    const int rc = make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms,
-                             workspace_bytes, ovr_of(ovr), &p, &t, &sa);
+    const int rc = make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
+                             hadamard_ovr(ovr_of(ovr), hadamard_size, num_bits, M, N, K), &p, &t, &sa);
     if (rc) return rc;
     if (P != num_bits * (N / 16)) return FLUTE_ERR_SHAPE;
     if (!A || !Q || !D || !S || !QM2) return FLUTE_ERR_NULL;

@@ -86,8 +86,11 @@ typedef struct flute_plan {
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
- *   family          0 decode kernel, 2 (or any other value >= 1) per-wave MFMA kernel, 3 block-tiled
- *                   prefill kernel (m_tiles 8 / 4 picks its 256 / 128-row block), 4 round-1 decode kernel
+ *   family          0 streaming decode kernel also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
+ *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
+ *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block;
+ *                   slabs_per_wave 1 / 2: the 2 x 4 wave split, lockstep / software-pipelined, 4-bit only),
+ *                   4 round-1 decode kernel
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split

@@ -59,11 +59,11 @@ def plan(M, N, K, bits=4, g=64, tid=16, sms=256, ws=64 << 20, dtype=0):
 
 
 def test_plan_families_and_invariants():
-    for bits, tid, dec_max in ((4, 16, 4), (2, 4, 4), (3, 4, 2)):
+    for bits, tid in ((4, 16), (2, 4), (3, 4)):
         for M in (1, 2, 3, 4, 5, 8, 16, 17, 64, 256, 1000):
             rc, p = plan(M, 4096, 4096, bits=bits, tid=tid)
             assert rc == 0
-            want = 0 if M <= dec_max else 2          # decode kernel up to its row limit, MFMA kernel beyond
+            want = 0 if M <= 2 else 2                # decode kernel for M <= 2 (its 4-row variant on request), MFMA kernel beyond
             if bits == 3 and M == 1000:
                 want = 3                             # 3 bits: the per-wave kernel is slow enough that 128 blocks already win
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
@@ -77,6 +77,16 @@ def test_plan_families_and_invariants():
                 assert p.k_per_split * p.splitk >= 4096 and p.k_per_split % 64 == 0
             else:
                 assert p.workspace_needed == 0 and p.k_per_split == 4096
+    # M = 3, 4: the MFMA kernel by default; the four-row decode variant on request (override family 0) and for
+    # small layers called with a Hadamard size (the rotation stays fused)
+    lib = _lib.get()
+    p = _lib.Plan()
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(family=0), p) == 0
+    assert p.family == 0 and p.m_block == 4
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 4096, 3584, 16, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 28672, 8192, 16, 256, 64 << 20) == 0
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 2, 28672, 8192, 16, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(1, 3, 64, 512, 3, 4096, 4096, 4, 256, 64 << 20) == 0
     # no workspace -> never a grid-level K split
     for M in (1, 16, 64):
         rc, p = plan(M, 512, 16384, ws=0)

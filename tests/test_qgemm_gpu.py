@@ -216,7 +216,8 @@ def test_decode_plan_shapes(env):
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
             for shp in shapes:
                 for num_sms in (env.num_sms, 4):
-                    ovr = dev.Overrides(**shp)
+                    ovr = dev.Overrides(family=0, **shp)           # (M = 3, 4 take the MFMA kernel unless asked)
+                    assert dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)["family"] == 0
                     out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr).cpu()
                     err = rel_err(out, ref)
                     assert err < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, shp, num_sms, err)
@@ -235,12 +236,12 @@ def test_decode_chunked_activations(env):
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 83)
         What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
         tid = template_ids_for(env.fa, bits, tile_p)[0]
-        plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, dev.Overrides(splitk=1))
+        plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, dev.Overrides(family=0, splitk=1))
         assert plan["family"] == 0 and (plan["k_chunks"] > 1 or bits == 3), plan     # 3-bit: 8 KB table, the rows fit
         X = (torch.randn(M, K) / 100).to(dtype)
         for shp in (dict(splitk=1), dict(waves=8, kw=8, splitk=1), dict(waves=6, kw=1, splitk=1), dict()):
             out = dev.qgemm_planned(X.to(d), Q.to(d), S.to(d), table.to(d), table2.to(d), env.ws, bits, g, tid,
-                                    env.num_sms, dev.Overrides(**shp)).cpu()
+                                    env.num_sms, dev.Overrides(family=0, **shp)).cpu()
             err = rel_err(out, X.float() @ What)
             assert err < tol_of(dtype), (bits, g, dtype, K, M, shp, err)
 
@@ -475,6 +476,7 @@ def test_qgemm_hadamard_fused_equals_two_launches(env):
     BIT-identical to hadamard_transform followed by qgemm (same fp32 butterflies, one rounding), for
     every block size the fused path takes, both dtypes, M up to the decode limit, K not a multiple
     of 512, chunked staging (large K) and the 3-bit / 2-bit kernels."""
+    from flute_amd import dev
     d = env.dev
     lib = env.fa._lib.get()
     cases = [(4, 32, 64, torch.float16, 1024, 512), (4, 64, 64, torch.bfloat16, 3584, 512),
@@ -494,8 +496,9 @@ def test_qgemm_hadamard_fused_equals_two_launches(env):
                                                       tid, env.num_sms, env.ws.numel()) == 1
                 X = (torch.randn(M, K) / 10).to(dtype).to(d)
                 fused = env.fa.qgemm_hadamard(X, Qd, Sd, td, t2d, env.ws, bits, g, h, tid, env.num_sms)
-                two = env.fa.qgemm(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, bits, g, tid,
-                                   env.num_sms)
+                # the same kernel on pre-rotated activations (M = 3, 4: the plain product would take the MFMA kernel)
+                two = dev.qgemm_planned(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, bits, g, tid,
+                                        env.num_sms, dev.Overrides(family=0))
                 assert torch.equal(fused, two), (bits, dtype, K, h, M)
     # plans that cannot fuse (MFMA kernel, blocks larger than 512) take the scratch path
     bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 2048, 512

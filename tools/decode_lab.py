@@ -66,7 +66,7 @@ def check():
                     rec = {"kind": "check", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K,
                            "N": N, "M": M, "shape": shp, "num_sms": sms}
                     try:
-                        ovr = dev.Overrides(**shp)
+                        ovr = dev.Overrides(**({"family": 0, **shp}))
                         out = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, sms, ovr)
                         out1 = dev.qgemm_planned(E, Q, S, table, table2, ws, bits, g, tid, sms, ovr)
                         torch.cuda.synchronize()
