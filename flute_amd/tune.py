@@ -75,9 +75,11 @@ def get_template_key(M, N, K, num_bits, group_size, num_sms, dtype, legacy=False
 
 
 def m_bucket(M: int) -> int:
-    """Batch sizes that share a tuned entry: the decode kernel's row counts 1..4 each, then powers of two."""
-    if M <= 4:
+    """Batch sizes that share a tuned entry: 1 and 2 (the decode kernel's row counts), 3-4, then powers of two."""
+    if M <= 2:
         return M
+    if M <= 4:
+        return 4
     b = 16
     while b < M and b < 4096:
         b *= 2
