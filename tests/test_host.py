@@ -184,7 +184,7 @@ def test_shipped_tuned_table_is_consistent():
         if tile_p:
             assert flute_amd.TEMPLATE_CONFIGS[(bits, tid)]["TileP"] == tile_p, key
     assert tune.lookup_tuned(1, 4096, 4096, 4, 64, 256, torch.float16) is not None
-    assert tune.m_bucket(3) == 3 and tune.m_bucket(5) == 16 and tune.m_bucket(17) == 32 and tune.m_bucket(10 ** 6) == 4096
+    assert tune.m_bucket(2) == 2 and tune.m_bucket(3) == 4 and tune.m_bucket(5) == 16 and tune.m_bucket(17) == 32 and tune.m_bucket(10 ** 6) == 4096
     # answered from the table: no CUDA device is touched
     tid = tune._tune(1, 4096, 4096, 4, 64, 256, torch.float16, torch.device("cpu"))
     assert tid == tune.lookup_tuned(1, 4096, 4096, 4, 64, 256, torch.float16)
