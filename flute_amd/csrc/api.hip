@@ -418,7 +418,11 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         while (slabs % (nw / kw)) kw <<= 1;
         const long wgs = (long)slabs / (nw / kw) * mtiles;
         int splitk = 1;
-        while (wgs * splitk * 2 <= (long)num_sms && K / (splitk * 2 * kw) >= 256) splitk *= 2;
+        // 3-bit layers have no lane-sharing variants (a wave = 16 units x 16 fields = 256 columns): the grid-level K
+        // split is their only way to fill the chip, down to 64 k per wave (4096^2 M = 16: 20.5 -> 14.5 us,
+        // 4096x14336: 30.8 -> 20.2 us)
+        const int k_min = (bits == 3) ? 64 : 256;
+        while (wgs * splitk * 2 <= (long)num_sms && K / (splitk * 2 * kw) >= k_min) splitk *= 2;
         if (ov.splitk > 0) splitk = ov.splitk;
         int kps = round_up(ceil_div(K, splitk), 32 * kw);
         splitk = ceil_div(K, kps);
