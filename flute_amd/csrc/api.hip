@@ -390,6 +390,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         int R = 1;
         while (!combo_ok(R, mt)) R *= 2;
         while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
+        // QuantMapMode digit 1 (4-bit ids): no lane sharing above M = 16 - the chip is filled by the grid K split
+        // instead (8192^2 M = 64: R = 1, MT = 4, split 2 26.2 us against R = 2, MT = 2 30.3; 4096^2 prefers R = 2:
+        // the tuner decides)
+        if (bits == 4 && (template_id % 4) == 1 && M > 16 && combo_ok(1, mt)) R = 1;
         if (ov.m_block > 0 && combo_ok(ov.m_block, mt)) R = ov.m_block;
         // SW = 2 slabs per wave (4-bit, no lane sharing, fp16 up to MT = 4 / bf16 up to MT = 2: the bf16 path
         // keeps a second accumulator set): every activation fragment then serves 8 column tiles and the

@@ -53,8 +53,9 @@ enum flute_status {
  *   tile_p        packed-layout parameter (32/64) - fixes the wire format
  *   stages        decode: which of the planner's ranked (waves, K split) shapes to launch (2 = best,
  *                 3/4/5 = the next ones); MFMA kernel: the neighbouring in-workgroup K splits
- *   lut_copies    the reference's QuantMapMode slot (1/32/16/8): MFMA kernel, 4-bit: automatic / one /
- *                 two slabs per wave.  The kernels always replicate the pair table 32x in LDS.
+ *   lut_copies    the reference's QuantMapMode slot (1/32/16/8): MFMA kernel, 4-bit: automatic / no lane sharing
+ *                 above M = 16 (the grid K split fills the chip instead) / one / two slabs per wave.  The kernels
+ *                 always replicate the pair table 32x in LDS.
  * The decode kernel applies the group scale in fp32 to an 8-k partial sum: exact on
  * one-hot inputs, within 2^-11 relative per term of the reference's round_T(lut * s) otherwise. */
 typedef struct flute_template_info {
