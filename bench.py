@@ -401,6 +401,31 @@ def main():
             del lay
             torch.cuda.empty_cache()
 
+        # prefill of the 3- and 2-bit layers (block kernels qgemm_block3.h / qgemm_block2.h), torch.mm of the same
+        # shape and dtype beside them
+        for (tag, m, n, k, b, dt) in (
+                ("W3G64 bf16 M=4096 K=4096 N=4096 prefill", 4096, 4096, 4096, 3, bf16),
+                ("W3G64 bf16 M=1024 K=8192 N=28672 prefill (configs[2] layer)", 1024, 28672, 8192, 3, bf16),
+                ("W2G64 fp16 M=4096 K=4096 N=4096 prefill", 4096, 4096, 4096, 2, dtype)):
+            lay = Layer(m, n, k, b, g, dt, device, copies_for(n, k, b), None)
+            lay.tune()
+            e_ms, _ = time_graph(lay, 30, 5, lambda: torch.cuda.synchronize())
+            wd = [torch.randn(k, n, device=device, dtype=dt) for _ in range(max(2, L3_BYTES // (2 * k * n) + 2))]
+            xd = torch.randn(m, k, device=device, dtype=dt)
+
+            class _MM2:
+                def step(self, i, wd=wd, xd=xd):
+                    return torch.mm(xd, wd[i % len(wd)])
+
+            d_ms, _ = time_graph(_MM2(), 30, 5, lambda: torch.cuda.synchronize())
+            us = e_ms / 30 * 1e3
+            extras.append({"workload": tag, "template_id": lay.template_id, "us": round(us, 3),
+                           "TFLOPs": round(lay.flops() / us / 1e6, 2),
+                           "frac_mfma_2.5PF": round(lay.flops() / us / 1e6 / MFMA_PEAK_TFLOPS, 4),
+                           "torch_mm_us": round(d_ms / 30 * 1e3, 3), "speedup_vs_torch_mm": round(d_ms / e_ms, 3)})
+            del lay, wd, xd
+            torch.cuda.empty_cache()
+
         # the one speed figure the reference publishes for this path (intro-figure.jpg, README.md:135-137):
         # qgemm against torch.mm in fp16, W4G128, N = K = 8192, batch 1..32 (A100 ~2.05x, A6000 ~3.1x)
         n = k = 8192
