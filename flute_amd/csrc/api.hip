@@ -297,8 +297,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
     else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
-    // columns; qgemm_block.h, the 2 x 4 wave split, stays reachable by override): 4-bit layers, scale rows in
-    // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
+    // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks; qgemm_block.h, the 2 x 4
+    // wave split of 4-bit layers, stays reachable by override); scale rows in whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
     //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
