@@ -139,7 +139,7 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     const int units = N / J;
     const int G = K >> lg;
     int mb = 1; while (mb < M) mb <<= 1;
-    const int dec_max = (bits == 3) ? 2 : 4;
+    const int dec_max = 4;
     if (ov.m_block > 0 && ov.m_block >= M && ov.m_block <= dec_max) mb = floor_pow2(ov.m_block);
     int depth = (bits == 3) ? 2 : (t.sms_multiple == 1 ? 4 : 2);
     if (ov.depth == 2 || (ov.depth == 4 && bits != 3)) depth = ov.depth;
@@ -229,7 +229,7 @@ int plan_legacy_decode(int bits, int lg, int M, int N, int K, int num_sms, const
                        const Ovr& ov, size_t workspace_bytes, flute_plan* p) {
     const int J = (bits == 3) ? 16 : 16 / bits;
     const int units = N / J, lines = K / 64;
-    const int dec_max = (bits == 3) ? 2 : 4;
+    const int dec_max = 4;
     int mb = 1; while (mb < M) mb <<= 1;
     if (ov.m_block > 0 && ov.m_block >= M && ov.m_block <= dec_max) mb = ov.m_block;
     int waves = t.threads / 64;
@@ -292,8 +292,11 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // Streaming decode kernel: M <= 2; its four-row variant (2- / 4-bit) only on request (override family 0, which
     // flute_qgemm_hadamard sets for small layers so that the rotation stays fused): measured at M = 3, 4 the MFMA
     // kernel is as fast on 4096^2 (7.6 vs 7.75 us) and 15-25 % faster on every larger layer (8192x28672: 38.6 vs 48.9).
-    const int dec_max = (bits == 3) ? 2 : 4;
-    int family = (M <= 2 || (M <= dec_max && ov.family == 0)) ? 0 : 2;
+    // (3-bit layers up to 24 M weights also take it by themselves: their MFMA plans are 256 columns wide per wave -
+    // 4096^2 M = 4: 9.9 against 13.7 us; larger 3-bit layers are faster on the MFMA kernel.)
+    const int dec_max = 4;
+    const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
+    int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
     if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
     else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
@@ -592,7 +595,7 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
 // M = 3, 4 with a Hadamard pre-rotation: the four-row decode kernel keeps the rotation fused (one launch) - worth
 // more than the MFMA kernel's edge on layers up to 32 M weights (4096x3584: 8.7 us fused vs 7.6 + a rotation launch)
 static Ovr hadamard_ovr(Ovr o, int hadamard_size, int bits, int M, int N, int K) {
-    if (hadamard_size > 1 && hadamard_size <= 512 && o.family < 0 && M >= 3 && M <= 4 && bits != 3 &&
+    if (hadamard_size > 1 && hadamard_size <= 512 && o.family < 0 && M >= 3 && M <= 4 &&
         (size_t)N * K <= ((size_t)32 << 20))
         o.family = 0;
     return o;

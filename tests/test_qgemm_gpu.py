@@ -207,7 +207,7 @@ def test_decode_plan_shapes(env):
         What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
         tid = template_ids_for(env.fa, bits, tile_p)[0]
         Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
-        for M in ((1, 2) if bits == 3 else (1, 2, 3, 4)):
+        for M in (1, 2, 3, 4):
             X = (torch.randn(M, K) / 100).to(dtype)
             ks = torch.randint(0, K, (M,))
             E = torch.zeros(M, K, dtype=dtype)
@@ -490,8 +490,6 @@ def test_qgemm_hadamard_fused_equals_two_launches(env):
             if K % h:
                 continue
             for M in (1, 2, 3, 4):
-                if bits == 3 and M > 2:
-                    continue
                 assert lib.flute_qgemm_hadamard_fused(0 if dtype == torch.float16 else 1, bits, g, h, M, N, K,
                                                       tid, env.num_sms, env.ws.numel()) == 1
                 X = (torch.randn(M, K) / 10).to(dtype).to(d)
