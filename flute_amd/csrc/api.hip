@@ -3,7 +3,7 @@
 // qgemm_kernel_raw_generated.cu:15-768 (_qgemm_raw's template switch) +
 // qgemm_kernel.hpp:824-939 (qgemm_host), re-thought for gfx950: instead of one
 // Stream-K kernel with 36/144 tile variants there are two kernel families
-// (streaming decode for M <= 4 - 3-bit: M <= 2 -, MFMA above) whose launch geometry is derived
+// (streaming decode for M <= 2 - on small layers M <= 4 -, MFMA above, block-tiled MFMA for prefill) whose launch geometry is derived
 // from the template's knobs and the problem shape.  Nothing here is process-global mutable state
 // except the per-device "large LDS granted" cache (mutex-guarded): plan overrides travel with the call.
 #include <hip/hip_runtime.h>

@@ -1,4 +1,5 @@
-// Decode-regime kernel, second generation (M <= 4; 3 bits: M <= 2): HBM-bound streaming LUT-dequant GEMV.
+// Decode-regime kernel, second generation (up to 4 rows per pass; the planner takes it for M <= 2, and for M <= 4 on
+// small layers - api.hip): HBM-bound streaming LUT-dequant GEMV.
 //
 // Replaces, for small M, the reference's qgemm_device main loop (flute/csrc/qgemm_kernel.hpp:617-712)
 // + Stream-K fixup (tile_scheduler_utils.hpp:58-211).  CDNA4 design, not a translation.  The round-1

@@ -63,7 +63,7 @@ def get_template_key(M, N, K, num_bits, group_size, num_sms, dtype, legacy=False
     """flute/tune.py:173-202 (there M < 16 shares a template; here 5 <= M <= 16 does)."""
     if legacy:
         return (num_sms, num_bits, group_size, M, N, K, str(dtype))
-    # the decode kernel (M <= 4) and the MFMA kernel read different knobs of a template
+    # the decode kernel (M <= 2, on small layers M <= 4) and the MFMA kernel read different knobs of a template
     return ("v1", M if M <= 4 else max(M, 16), N, K, num_bits, group_size, num_sms, dtype)
 
 
@@ -252,7 +252,7 @@ def check(weight: torch.Tensor, weight_packed: torch.Tensor, metadata: TuneMetaD
     if identity:
         if not (output_ == output).all().item():
             raise AssertionError(f"[FLUTE] identity check failed: {metadata}")
-        # M = K runs the MFMA kernels; the streaming decode kernel (M <= 4) applies the group scale in fp32 to an
+        # M = K runs the MFMA kernels; the streaming decode kernel (M <= 2 / 4) applies the group scale in fp32 to an
         # 8-k partial sum - exact on one-hot rows: check it on the first / last / middle rows of the identity
         rows = torch.tensor([0, metadata.K // 2, metadata.K - 1, 1][: (2 if metadata.num_bits == 3 else 4)], device=dev)
         for m in (1, rows.numel()):

@@ -118,7 +118,8 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
 
 /* flute.qgemm_hadamard (flute/__init__.py:32-50; apply_hadamard + qgemm_raw_simple_hadamard,
  * flute/csrc/qgemm.cpp:201-244): D = (A.reshape(-1, hadamard_size) @ H/sqrt(hadamard_size)).reshape(M,K)
- * @ dequant(Q).  When the launch plan is the decode kernel (M <= 4) and hadamard_size <= 512 divides K,
+ * @ dequant(Q).  When the launch plan is the decode kernel (M <= 2; M <= 4 on layers up to 32 M weights) and
+ * hadamard_size <= 512 divides K,
  * the rotation is fused into that kernel's activation staging (one launch, no round trip of the
  * rotated activations through HBM; same fp32 butterflies and single rounding as flute_hadamard, so the
  * result is bit-identical to the two-launch form).  Otherwise the rotated activations go to
