@@ -40,6 +40,9 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
+// rows of a block-kernel configuration (flute_plan::m_block of family 3): 0..7 = 256 / 128 rows (even / odd),
+// 8 + RT = the skinny 3-bit blocks of RT row tiles
+int block_rows(int cfg) { return cfg >= 8 ? (cfg - 8) * 16 : ((cfg & 1) ? 128 : 256); }
 
 // Template id -> knobs.  Enumeration order is the reference's
 // (flute/codegen_utils.py:110-152): SMs_Multiple {1,2,4} x tile {0,1,2} x
@@ -318,7 +321,14 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (ov.slabs == 2) blk_cfg |= 2;
             else if (ov.slabs != 1) blk_cfg += 4;
             if (bits == 2) blk_cfg = 4 + (blk_cfg & 1);      // the 2 x 4 split (either schedule) exists for 4-bit layers only
-            if (bits == 3) blk_cfg = 5;                      // 3-bit layers: 128-row blocks of qgemm_block3.h only
+            if (bits == 3) blk_cfg = 5;                      // 3-bit layers: 128-row blocks of qgemm_block3.h ...
+            if (bits == 3 && (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4))
+                blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
+        } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)48 << 20)) {
+            // 3-bit skinny blocks (64 rows, grid K split): measured against the per-wave kernel at M = 64 - 8192^2 31.6 vs
+            // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (a K step of
+            // a skinny block is shorter than the memory latency its two-step prefetch has to cover)
+            blk_cfg = 12;
         } else if (M >= 256) {
             const bool bf = dtype == FLUTE_BF16;
             auto block_us = [&](long tiles, double alone, double busy) {
@@ -350,10 +360,12 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
-        const int tm = (blk_cfg & 1) == 0 ? 8 : 4, bm = tm * 32;      // block rows / 32
+        const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
-        int splitk = (ov.splitk > 0) ? ov.splitk : 1;
         const int align_k = std::max(64, 8 << lg);
+        int splitk = (ov.splitk > 0) ? ov.splitk : 1;
+        if (blk_cfg >= 8 && ov.splitk <= 0)                  // skinny blocks: the K split fills the chip
+            while ((long)tiles_m * tiles_n * splitk * 2 <= (long)num_sms && K / (splitk * 2) >= std::max(256, align_k)) splitk *= 2;
         int kps = round_up(ceil_div(K, splitk), align_k);
         splitk = ceil_div(K, kps);
         while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
@@ -678,7 +690,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.QM2 = reinterpret_cast<const uint32_t*>(QM2);
         b.partial = reinterpret_cast<float*>(workspace);
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
-        const int bm = p.m_tiles * 32;
+        const int bm = block_rows(p.m_block);
         b.tiles_m = ceil_div(M, bm); b.tiles_n = N / 256;
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
         // XCD x (block id % 8) owns a contiguous range of row blocks (their activations then stay in its L2

@@ -26,9 +26,15 @@ template <typename T, int RT>
 __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args) {
     using NT = Num<T>;
     constexpr int BITS = 3, TILEP = 32;
-    static_assert(RT == 8, "128-row blocks (the weight ring leaves no registers for 16 row tiles)");
+    // RT = 8: 128-row blocks (the weight ring leaves no registers for 16 row tiles).  RT = 1, 2, 4: "skinny" blocks of
+    // 16 / 32 / 64 rows for small batches, launched with a grid-level K split (fp32 slabs + splitk_reduce_kernel): a
+    // 3-bit wave of the per-wave kernel is 256 columns wide, so a 4096-wide layer gives it 16 column slabs; here the
+    // same layer gives 16 column blocks x the K split, every weight looked up once.
+    static_assert(RT == 8 || RT == 4 || RT == 2 || RT == 1, "row tiles per block");
     constexpr int NW = 8, BM = RT * 16, NT2 = 2;
-    constexpr int PIECES = RT * 2, PPW = PIECES / NW, PH = PPW;
+    constexpr int PIECES = RT * 2;                                 // 1-KB activation pieces per stage
+    constexpr int PH = (PIECES + NW - 1) / NW;                     // ... requested by a wave (skinny blocks: one, some of them idle)
+    constexpr int LPR = 8 / RT;                                    // lookups issued after every row tile
     constexpr int LUT_BYTES = 64 * 128;
     constexpr int STAGE_BYTES = PIECES * 1024;
 
@@ -75,11 +81,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
     const srd_t w_srd = make_srd(a.Q, (uint32_t)min((size_t)(3 * (a.N >> 4)) * row_bytes, (size_t)0xfffffff0u));
     const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
-    const int p0 = wave * PPW;
-    const uint32_t x_v0 = (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
-                                      ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2);
+    const int p0 = wave * PH;
+    const bool x_mine = p0 < PIECES;                               // (wave-uniform) skinny blocks have fewer pieces than waves
+    const uint32_t x_v0 = x_mine ? (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
+                                               ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2) : 0x80000000u;
     const uint32_t x_dv = 16u * row_bytes;
-    const uint32_t x_lds0 = (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u;
     // plane rows of this lane's unit (common.h unit_row<3>): plane 0 = row u, planes 1 / 2 = 32 rows apart
     const int u = unit0 + r16;
     const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const uint32_t wv_dp = 32u * row_bytes;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
+    const uint32_t x_lds0 = x_mine ? (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u : sc_sink;     // idle request: zeros into the sink
 
     {   // pair table: 64 entries, 32 copies each (128-B stride)
         for (int p = tid; p < 64 * 8; p += NW * 64) {
@@ -105,9 +112,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         constexpr bool LAST = KIND == 2;
         constexpr int NPL = KIND + 1;                              // weight pieces per half step
         constexpr int BATCH = PH + 2 * NPL + 1;
-        constexpr int NA = BATCH < RT ? BATCH : RT;                // requests issued during half step 0 (one per row tile)
-        constexpr int NB = BATCH - NA;                             // ... during half step 1
-        static_assert(NB <= RT, "batch too long");
+        constexpr int RPR = (BATCH + RT - 1) / RT;                 // requests issued after every row tile of half step 0
         // tile t = field f_t: plane, bit offset (wave-uniform), this lane's row offset of that plane
         const int f0 = (wave < 6) ? (wave >> 1) + 6 * (wave & 1) : 2 * wave;          // 0 6 1 7 2 8 | 12 | 14
         const int f1 = (wave < 6) ? f0 + 3 : f0 + 1;                                   // 3 9 4 10 5 11 | 13 | 15
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             constexpr int i = decltype(i_tag)::value;
             const uint32_t k0 = (uint32_t)(kbeg + min(ustep, nsteps - 1) * 64);
             if constexpr (i < PH) {
-                dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+                dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u,
+                          x_lds0 + (x_mine ? (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES : 0u));
             } else if constexpr (i < PH + 2 * NPL) {
                 constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;
                 uint32_t vo;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         uint32_t v[8];                                             // hidden lookups of the NEXT half step: [tile][word]
-        u32x4_t af[8];                                             // fragment slots = the 8 row tiles
+        u32x4_t af[RT];                                            // fragment slots = the row tiles
         uint32_t scn[NT2];
 
         auto scales = [&](int t, int h) {
@@ -202,11 +208,27 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
         };
         auto wait_lds = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                           "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
-                           "+v"(scn[0]), "+v"(scn[1])
-                         : : "memory");
+            if constexpr (RT == 8)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(af[0]), "+v"(af[1 % RT]), "+v"(af[2 % RT]), "+v"(af[3 % RT]), "+v"(af[4 % RT]), "+v"(af[5 % RT]),
+                               "+v"(af[6 % RT]), "+v"(af[7 % RT]), "+v"(scn[0]), "+v"(scn[1])
+                             : : "memory");
+            else if constexpr (RT == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(af[0]), "+v"(af[1 % RT]), "+v"(af[2 % RT]), "+v"(af[3 % RT]), "+v"(scn[0]), "+v"(scn[1])
+                             : : "memory");
+            else if constexpr (RT == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(af[0]), "+v"(af[1 % RT]), "+v"(scn[0]), "+v"(scn[1])
+                             : : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(af[0]), "+v"(scn[0]), "+v"(scn[1])
+                             : : "memory");
         };
 
         auto half = [&](auto slot_tag, auto h_tag, int t) {
@@ -218,8 +240,8 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             if constexpr (h == 0) {
                 __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free: batch t+2 follows, spread over the rows
             } else {
-                // (B) batch t+1 has landed once at most the NA requests of batch t+2 issued so far are outstanding
-                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, NA>{});
+                // (B) batch t+1 has landed once at most batch t+2 (issued during half step 0) is outstanding
+                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, BATCH>{});
                 __builtin_amdgcn_s_barrier();
             }
             u32x4_t bf[NT2];
@@ -233,12 +255,18 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 constexpr int R = decltype(r_tag)::value;
 #pragma unroll
                 for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
-                if constexpr (h == 0 && R < NA)
-                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, r_tag, t + 2);
-                if constexpr (h == 1 && R < NB)
-                    issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, NA + R>{}, t + 2);
+                if constexpr (h == 0)                              // batch t+2: RPR requests after every row tile
+                    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                        (([&] {
+                            if constexpr (R * RPR + Q < BATCH)
+                                issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{},
+                                          std::integral_constant<int, R * RPR + Q>{}, t + 2);
+                        }()), ...);
+                    }(std::make_integer_sequence<int, RPR>{});
                 frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
-                lookup(qw, r_tag);
+                [&]<int... L>(std::integer_sequence<int, L...>) {
+                    (lookup(qw, std::integral_constant<int, R * LPR + L>{}), ...);
+                }(std::make_integer_sequence<int, LPR>{});
             };
             [&]<int... R>(std::integer_sequence<int, R...>) {
                 (row(std::integral_constant<int, R>{}), ...);
@@ -254,7 +282,9 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             const u32x4_t (&qw)[NPL] = w[0][0];
             [&]<int... R>(std::integer_sequence<int, R...>) {
                 (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
-                (lookup(qw, std::integral_constant<int, R>{}), ...);
+            }(std::make_integer_sequence<int, RT>{});
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (lookup(qw, std::integral_constant<int, L>{}), ...);
             }(std::make_integer_sequence<int, 8>{});
         }
         auto step = [&](auto slot_tag, int t) {

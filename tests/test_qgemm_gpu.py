@@ -335,6 +335,28 @@ def test_block_prefill_kernel(env):
                 assert err < tol_of(dtype), (tile_p, g, dtype, K, N, M, shp, err)
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1, ref1), (tile_p, g, dtype, K, N, M, shp)
+    # 3-bit skinny blocks (16 / 32 / 64 rows, grid K split: qgemm_block3.h RT = 1, 2, 4)
+    bits, tile_p, g, dtype, K, N = 3, 32, 64, torch.bfloat16, 2048, 1024
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=77)
+    What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+    for M in (5, 16, 17, 40, 64, 90):
+        X = (torch.randn(M, K) / 100).to(dtype)
+        ks = torch.randint(0, K, (M,))
+        E = torch.zeros(M, K, dtype=dtype)
+        E[torch.arange(M), ks] = 1
+        ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+        for rt in (1, 2, 4):
+            for sk in (-1, 1):
+                ovr = dev.Overrides(family=3, m_block=rt, splitk=sk)
+                assert dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)["m_block"] == 8 + rt
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert rel_err(out, X.float() @ What) < tol_of(dtype), (M, rt, sk)
+                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert torch.equal(out1, ref1), (M, rt, sk)
+    p = dev.get_plan(64, 8192, 8192, 3, 64, 4, 256, torch.bfloat16)
+    assert p["family"] == 3 and p["m_block"] == 12 and p["splitk"] > 1, p
     # the planner takes it by itself where the output has enough blocks
     p = dev.get_plan(4096, 4096, 4096, 4, 64, 16, 256, torch.float16)
     assert p["family"] == 3 and p["m_block"] == 4 and p["grid"] == 256, p           # 256-row blocks, 1 x 8 split

@@ -41,8 +41,48 @@ def regs_of(text):
     return out
 
 
+def _sgpr_mentions(text, n):
+    """(is_mentioned, only_as_destination) of SGPR n in one instruction."""
+    ops = text.split(None, 1)
+    if len(ops) < 2:
+        return False, False
+    parts = [o.strip() for o in ops[1].split(",")]
+
+    def has(tok):
+        if re.search(r"\bs%d\b" % n, tok):
+            return True
+        for m in re.finditer(r"s\[(\d+):(\d+)\]", tok):
+            if int(m.group(1)) <= n <= int(m.group(2)):
+                return True
+        return False
+    hits = [has(t) for t in parts]
+    if not any(hits):
+        return False, False
+    return True, hits[0] and not any(hits[1:]) and not ops[0].startswith(("s_cmp", "s_cbranch", "s_bitcmp"))
+
+
+def _dead_readfirstlane(lines, i, text):
+    """hipcc materialises an UNDEF scalar with `v_readfirstlane_b32 sN, <any vgpr>`: the value is dead when sN is
+    overwritten before it is read.  Follows the fall-through path only (a taken branch in between = not proven)."""
+    m = re.match(r"v_readfirstlane_b32\s+s(\d+),", text)
+    if not m:
+        return False
+    n = int(m.group(1))
+    for raw in lines[i + 1:i + 80]:
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":") or t.startswith(";;"):
+            continue
+        mentioned, dest_only = _sgpr_mentions(t, n)
+        if mentioned:
+            return dest_only
+        if t.startswith(("s_branch", "s_endpgm", "s_setpc")):
+            return False
+    return False
+
+
 def audit(path):
     findings = []
+    all_lines = open(path).read().split("\n")
     kernel = None
     in_asm = False
     vm_fifo = []          # hidden VMEM loads in flight: (line number, set of VGPRs)
@@ -113,7 +153,7 @@ def audit(path):
         for _, r in ds_set:
             busy |= r
         hit = used & busy
-        if hit:
+        if hit and not _dead_readfirstlane(all_lines, ln - 1, text):
             findings.append((kernel, ln, text, sorted(hit)))
     return findings
 
