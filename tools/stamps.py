@@ -20,6 +20,7 @@ lib = _lib.get()
 f16 = torch.float16
 FAM = int(os.environ.get("STAMPS_FAMILY", "2"))
 dec_cases = [      # streaming decode kernel: (family 0, rows, waves, kw, splitk, -, -, ring depth)
+    (1, 4096, 4096, (0, -1, -1, -1, -1, -1, -1, -1)),        # the planner's own choice: the one-shot variant
     (1, 4096, 4096, (0, -1, 8, 2, 1, -1, -1, 4)),
     (1, 4096, 4096, (0, -1, 16, 4, 1, -1, -1, 4)),
     (1, 4096, 4096, (0, -1, 16, 4, 1, -1, -1, 2)),
