@@ -13,3 +13,44 @@ def test_no_instruction_touches_an_in_flight_hidden_load():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 finding(s)") == 6, r.stdout[-2000:]
+
+
+def _audit_text(tmp_path, body):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_asm_loads", os.path.join(ROOT, "tools", "audit_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    f = tmp_path / "k.s"
+    f.write_text("_Z6kernelv:\n" + body + "\ts_endpgm\n")
+    return mod.audit(str(f))
+
+
+def test_audit_rules_on_synthetic_streams(tmp_path):
+    """The lint itself: what it must flag and what it must not."""
+    load = "\t;;#ASMSTART\n\tbuffer_load_dwordx4 v[4:7], v1, s[0:3], s8 offen\n\t;;#ASMEND\n"
+    wait0 = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
+    # a copy of the in-flight destination before the wait (the round-2 failure) is flagged ...
+    assert len(_audit_text(tmp_path, load + "\tv_mov_b32_e32 v20, v4\n" + wait0)) == 1
+    # ... the same copy after the wait is not
+    assert _audit_text(tmp_path, load + wait0 + "\tv_mov_b32_e32 v20, v4\n") == []
+    # counted waits release the OLDEST loads only
+    two = load + "\t;;#ASMSTART\n\tbuffer_load_dwordx4 v[8:11], v1, s[0:3], s8 offen\n\t;;#ASMEND\n"
+    wait1 = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n"
+    assert _audit_text(tmp_path, two + wait1 + "\tv_add_u32_e32 v20, v4, v5\n") == []
+    assert len(_audit_text(tmp_path, two + wait1 + "\tv_add_u32_e32 v20, v8, v5\n")) == 1
+    # LDS-DMA writes no VGPR: its first operand is the address and may be reused at once
+    dma = "\t;;#ASMSTART\n\tbuffer_load_dwordx4 v3, s[4:7], s9 offen lds\n\t;;#ASMEND\n\tv_mov_b32_e32 v3, 0\n"
+    assert _audit_text(tmp_path, dma) == []
+    # hidden LDS reads: in-order return, counted lgkmcnt
+    lds = ("\t;;#ASMSTART\n\tds_read_b32 v30, v2\n\t;;#ASMEND\n\t;;#ASMSTART\n\tds_read_b32 v31, v2\n\t;;#ASMEND\n")
+    lg1 = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(1)\n\t;;#ASMEND\n"
+    assert _audit_text(tmp_path, lds + lg1 + "\tv_mov_b32_e32 v40, v30\n") == []
+    assert len(_audit_text(tmp_path, lds + lg1 + "\tv_mov_b32_e32 v40, v31\n")) == 1
+    # an MFMA reading a fragment whose hidden read is still outstanding (the qgemm_block2.h bug) is flagged
+    frag = "\t;;#ASMSTART\n\tds_read_b128 v[30:33], v2 offset:1024\n\t;;#ASMEND\n"
+    assert len(_audit_text(tmp_path, frag + "\tv_mfma_f32_16x16x32_f16 v[60:63], v[50:53], v[30:33], v[60:63]\n")) == 1
+    # hipcc's undef placeholder: a readfirstlane of any register whose scalar result is overwritten before use
+    undef = load + "\tv_readfirstlane_b32 s10, v4\n\ts_add_i32 s10, s46, 64\n" + wait0
+    assert _audit_text(tmp_path, undef) == []
+    live = load + "\tv_readfirstlane_b32 s10, v4\n\ts_add_i32 s11, s10, 64\n" + wait0
+    assert len(_audit_text(tmp_path, live)) == 1
