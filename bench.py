@@ -238,7 +238,8 @@ def tp_mlp_pair(world, rank, device, dist, pairs=50, warmup=5):
         mode = "hipGraph"
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 body(collective, pairs)
             graph.replay()
             sync()

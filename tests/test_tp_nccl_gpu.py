@@ -77,7 +77,7 @@ def _worker(rank, world, port, bits, tile_p, g, dtype_name, result):
             eager = down(col_s(Xd))
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (the watchdog thread stays legal)
                 out = down(col_s(Xd))
             graph.replay()
             torch.cuda.synchronize()
