@@ -326,8 +326,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
         } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)48 << 20)) {
             // 3-bit skinny blocks (64 rows, grid K split): measured against the per-wave kernel at M = 64 - 8192^2 31.6 vs
-            // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (a K step of
-            // a skinny block is shorter than the memory latency its two-step prefetch has to cover)
+            // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (fixed
+            // costs of ~8 us per call: prologue, fp32 slabs, reduce launch)
             blk_cfg = 12;
         } else if (M >= 256) {
             const bool bf = dtype == FLUTE_BF16;

@@ -35,6 +35,10 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     constexpr int PIECES = RT * 2;                                 // 1-KB activation pieces per stage
     constexpr int PH = (PIECES + NW - 1) / NW;                     // ... requested by a wave (skinny blocks: one, some of them idle)
     constexpr int LPR = 8 / RT;                                    // lookups issued after every row tile
+    // stages = ring slots: batch t + NST - 1 is requested during step t.  (Six stages for the skinny blocks measured
+    // SLOWER than three - 4096^2 M = 16: 18.5 vs 15.8 us: they are not latency-bound; what they pay is the fixed part,
+    // prologue + fp32 slabs + the reduce launch, ~8 us of a 16-us call.)
+    constexpr int NST = BLK_STAGES;
     constexpr int LUT_BYTES = 64 * 128;
     constexpr int STAGE_BYTES = PIECES * 1024;
 
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_p1 = (uint32_t)((a.N >> 4) + (u >> 5) * 64 + (u & 31)) * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_dp = 32u * row_bytes;
-    const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
+    const uint32_t sc_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
     const uint32_t x_lds0 = x_mine ? (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u : sc_sink;     // idle request: zeros into the sink
 
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         const uint32_t s_voff = (lane < 32)
             ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 15)) + ((lane >> 4) ? f1 : f0) * TILEP) * a.G) * 2) : 0x80000000u;
 
-        u32x4_t w[BLK_STAGES][2][NPL];
+        static_assert((NST - 2) * BATCH <= 63, "vmcnt is six bits");
+        u32x4_t w[NST][2][NPL];
         auto issue_one = [&](auto slot_tag, auto i_tag, int ustep) {
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int i = decltype(i_tag)::value;
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ws[0][0]), "+v"(ws[1][0]) : "n"(n) : "memory");
         };
 
-        issue_batch(std::integral_constant<int, 0>{}, 0);
-        issue_batch(std::integral_constant<int, 1>{}, 1);
+        [&]<int... I>(std::integer_sequence<int, I...>) {            // batches 0 .. NST-2
+            (issue_batch(std::integral_constant<int, I>{}, I), ...);
+        }(std::make_integer_sequence<int, NST - 1>{});
 
         f32x4_t acc[RT][NT2];
 #pragma unroll
@@ -234,14 +240,14 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         auto half = [&](auto slot_tag, auto h_tag, int t) {
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int h = decltype(h_tag)::value;
-            constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;
+            constexpr int nslot = h ? (slot + 1) % NST : slot;
             constexpr int nh = h ^ 1;
             wait_lds();
             if constexpr (h == 0) {
-                __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free: batch t+2 follows, spread over the rows
+                __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free: batch t+NST-1 follows, spread over the rows
             } else {
-                // (B) batch t+1 has landed once at most batch t+2 (issued during half step 0) is outstanding
-                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, BATCH>{});
+                // (B) batch t+1 has landed once at most batches t+2 .. t+NST-1 are outstanding
+                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, (NST - 2) * BATCH>{});
                 __builtin_amdgcn_s_barrier();
             }
             u32x4_t bf[NT2];
@@ -255,12 +261,12 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 constexpr int R = decltype(r_tag)::value;
 #pragma unroll
                 for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
-                if constexpr (h == 0)                              // batch t+2: RPR requests after every row tile
+                if constexpr (h == 0)                              // batch t+NST-1: RPR requests after every row tile
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         (([&] {
                             if constexpr (R * RPR + Q < BATCH)
-                                issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{},
-                                          std::integral_constant<int, R * RPR + Q>{}, t + 2);
+                                issue_one(std::integral_constant<int, (slot + NST - 1) % NST>{},
+                                          std::integral_constant<int, R * RPR + Q>{}, t + NST - 1);
                         }()), ...);
                     }(std::make_integer_sequence<int, RPR>{});
                 frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         };
 
         // batch 0 and the pair table before anyone reads them
-        wait_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, BATCH>{});
+        wait_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, (NST - 2) * BATCH>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         scales(0, 0);
@@ -291,18 +297,17 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             half(slot_tag, std::integral_constant<int, 0>{}, t);
             half(slot_tag, std::integral_constant<int, 1>{}, t);
         };
-        for (int t0 = 0;; t0 += BLK_STAGES) {                      // unrolled by the ring, left after the LAST step
-            step(std::integral_constant<int, 0>{}, t0);
-            if (t0 + 1 >= nsteps) break;
-            step(std::integral_constant<int, 1>{}, t0 + 1);
-            if (t0 + 2 >= nsteps) break;
-            step(std::integral_constant<int, 2>{}, t0 + 2);
-            if (t0 + 3 >= nsteps) break;
-        }
+        // unrolled by the ring (the slots are compile-time), left after the LAST step
+        auto round = [&]<int... I>(std::integer_sequence<int, I...>, int t0) -> bool {
+            bool done = false;
+            ((done = done || (step(std::integral_constant<int, I>{}, t0 + I), t0 + I + 1 >= nsteps)), ...);
+            return done;
+        };
+        for (int t0 = 0; !round(std::make_integer_sequence<int, NST>{}, t0); t0 += NST) {}
         wait_lds();                                                // the prefetch past the end
-        wait_batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        wait_batch(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        wait_batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (wait_batch(std::integral_constant<int, I>{}, std::integral_constant<int, 0>{}), ...);
+        }(std::make_integer_sequence<int, NST>{});
 
         // ---- epilogue: accumulator register i of lane (r16, q4) = unit 4 q4 + i of the workgroup, i.e. four
         // consecutive columns of field f_t; the lane's output row is r16 ----
