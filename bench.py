@@ -16,16 +16,15 @@ Rank 0 prints ONE JSON line (contract in the task description) carrying
 stream) and `cpu_baseline` (the CPU oracle = the reference's test formula,
 dequant + torch.mm, timed on this host's cores).
 
-N > 1 (one process per GPU, RCCL): the headline becomes BASELINE.json
-configs[3] - the Llama-3-70B MLP pair 8192x28672 -> 28672x8192 sharded N-way
-(column-parallel up projection, row-parallel down projection, ONE all-reduce
-of M*8192*2 B), the two launches AND the collective of 50 pairs captured in one
-hipGraph, barrier + max-over-ranks; `value` = bytes of the whole (unsharded)
-pair / that time, "scaling": "strong".  The independent-replica figure of the
-single-GPU headline (no collective, weak scaling) rides along as `replicas`.
-N = 1: the same pair at TP = 1 is an extra (`tp_mlp_pair`), together with the
-other BASELINE configs, prefill shapes with torch.mm fp16 beside them, and the
-CPU baseline.
+N > 1 (one process per GPU, RCCL): the headline stays the same workload - N
+independent replicas, no collective, barrier + max-over-ranks, `value` = N x
+bytes / time, "scaling": "weak" - so that the per-N values are comparable.
+BASELINE.json configs[3] - the Llama-3-70B MLP pair 8192x28672 -> 28672x8192
+sharded N-way (column-parallel up projection, row-parallel down projection,
+ONE all-reduce of M*8192*2 B), launches AND collective captured in one
+hipGraph - is reported under `tp_mlp_pair` (strong scaling; N = 1: TP = 1),
+next to the other BASELINE configs, prefill shapes with torch.mm fp16 beside
+them, and the CPU baseline.
 """
 import argparse
 import json
@@ -115,9 +114,25 @@ def copies_for(N, K, bits, cap_bytes=3 << 30):
     return int(max(2, min(n, cap_bytes // per)))
 
 
-def time_graph(layer, steps, warmup, sync):
+_FLUSH = {}
+
+
+def flush_l3(device):
+    """Untimed: push everything out of the 256 MiB Infinity Cache (and the L2s) by READING a 512 MiB scratch
+    buffer (read-only: no dirty lines whose write-back would compete with the timed reads), so that the timed
+    replay streams its weights from HBM whatever --steps is (20 steps of the headline touch 178 MB: without this
+    the warm replays would leave them cache-resident)."""
+    buf = _FLUSH.get(device)
+    if buf is None:
+        buf = _FLUSH[device] = torch.zeros(2 * L3_BYTES // 4, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+    return int(buf.sum().item())                      # .item(): the flush has finished before the timed region starts
+
+
+def time_graph(layer, steps, warmup, sync, cold=True):
     """Capture `steps` launches in one hipGraph, replay once, timed by HIP events on
-    the replay stream and by the host clock around sync()."""
+    the replay stream and by the host clock around sync().  cold: flush the caches (untimed) before the timed
+    replay."""
     for i in range(warmup):
         layer.step(i)
     torch.cuda.synchronize()
@@ -128,6 +143,8 @@ def time_graph(layer, steps, warmup, sync):
     for _ in range(3):                  # untimed: the first replay pays the upload, the next ones settle the clocks
         graph.replay()
     torch.cuda.synchronize()
+    if cold:
+        flush_l3(torch.device("cuda", torch.cuda.current_device()))
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync()
     t0 = time.perf_counter()
@@ -336,7 +353,7 @@ def main():
     # cache-resident variant (one copy, served by L2 / Infinity Cache)
     hot = Layer(M, N, K, bits, g, dtype, device, 1, NF4_VALUES, seed=rank)
     hot.template_id = tid
-    hot_ms, _ = time_graph(hot, args.steps, args.warmup, lambda: torch.cuda.synchronize())
+    hot_ms, _ = time_graph(hot, args.steps, args.warmup, lambda: torch.cuda.synchronize(), cold=False)
 
     # Llama-3-70B MLP pair (configs[3]): with a process group it is the headline (strong scaling, one RCCL
     # all-reduce inside the captured graph); on one GPU it is an extra (TP = 1, no collective)
@@ -460,14 +477,14 @@ def main():
         # HBM bytes per launch from the committed PMC passes of THIS command (tools/prof_bench.sh writes the file
         # together with the plan it profiled): reported only while the plan is still the one that was profiled
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_traffic.json")))     # newest round last
+        if tpaths:
+            tj = json.load(open(tpaths[-1]))
             if tj.get("plan") == plan:
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/r02_bench_traffic.json"
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(tpaths[-1])
         replicas = {
             "metric": "qgemm effective GB/s, M=1, W4G64 NF4 fp16, K=N=4096 (Llama-3-8B linear), HBM-cold",
-            "value": round(value, 2), "ms_per_step": round(ms_per_step, 6), "scaling": "weak",
             "parallelism": f"{world} independent replica(s), no collective"}
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
@@ -486,7 +503,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random codes/scales, NF4 table, X=randn/100; "
-                    f"{len(layer.Q)} rotating weight copies > 256 MiB L3)",
+                    f"{len(layer.Q)} rotating weight copies > 256 MiB L3; caches flushed (untimed) before the timed replay)",
+            "working_set_bytes": min(args.steps, len(layer.Q)) * (2 * (bits * N // 16) * K + 2 * N * K // g),
+            "timed_replay_cold": "untimed 512 MiB read between the warm replays and the timed replay: every "
+                                 "timed step streams its weights from HBM for any --steps",
             "config": {"workload": "W4G64 NF4 fp16 qgemm, M=1, K=4096, N=4096 (BASELINE configs[1])",
                        "template_id": tid, "plan": plan,
                        "launch": "hipGraph replay of all steps",
@@ -498,29 +518,10 @@ def main():
             "wall_ms_timed_region": round(wall_ms, 3),
             "extras": extras,
         }
-        if dist is not None and tp_pair is not None and "kernels_plus_allreduce_us" in tp_pair:
-            # N > 1: the north-star multi-GPU workload is the headline - the column-parallel / row-parallel pair
-            # with its ONE all-reduce; the replica figure of the single-GPU headline moves to `replicas`
-            t_us = tp_pair["kernels_plus_allreduce_us"]
-            per_gpu = tp_pair["whole_job_bytes"] / world
-            out.update({
-                "metric": "qgemm effective GB/s, M=1, W4G64 fp16, Llama-3-70B MLP pair 8192x28672 -> 28672x8192, "
-                          "tensor-parallel over all GPUs incl. the RCCL all-reduce, HBM-cold",
-                "value": tp_pair["whole_job_GBps_with_allreduce"], "ms_per_step": round(t_us / 1e3, 6),
-                "scaling": "strong", "steps": max(1, min(args.steps, 500)),
-                "config": {"workload": tp_pair["workload"] + " (BASELINE configs[3])",
-                           "template_ids": tp_pair["template_ids"], "launch": tp_pair["launch"],
-                           "parallelism": f"tp{world}: N-sharded up projection, K-sharded down projection, 1 all-reduce of "
-                                          f"{tp_pair['allreduce_bytes']} B per pair",
-                           "step": "one MLP pair (two qgemm launches + one all-reduce); --steps pairs (at most 500) are "
-                                   "captured in one hipGraph and ONE replay is timed"},
-                "roofline": {"bound": "hbm", "achieved": round(per_gpu / tp_pair["kernels_us"] / 1e3, 2),
-                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": round(per_gpu / tp_pair["kernels_us"] / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
-                             "bytes_per_launch_pair": per_gpu, "kernel_us_events": tp_pair["kernels_us"],
-                             "note": "per GPU: algorithmic bytes of its two shards / time of the two kernels (no collective)"},
-                "replicas": replicas,
-            })
+        # The headline metric is the SAME for every N (the driver computes scaling efficiency from the per-N values):
+        # N independent replicas of the single-GPU workload, no collective, weak scaling.  The tensor-parallel
+        # workload of BASELINE configs[3] - the column-parallel / row-parallel MLP pair with its ONE RCCL
+        # all-reduce, captured in one hipGraph - is reported under its own key `tp_mlp_pair` (strong scaling).
         if tp_pair is not None:
             out["tp_mlp_pair"] = tp_pair
         if dist is None and not args.no_cpu:

@@ -35,11 +35,11 @@ class Plan(ctypes.Structure):
 class Overrides(ctypes.Structure):
     """Per-call launch-plan overrides (include/flute_amd.h `flute_overrides`); -1 = automatic."""
     _fields_ = [(n, c_int) for n in (
-        "family", "m_block", "waves", "kw", "splitk", "m_tiles", "slabs_per_wave", "ring_depth")]
+        "family", "m_block", "waves", "kw", "splitk", "m_tiles", "slabs_per_wave", "ring_depth", "one_shot")]
 
     def __init__(self, family=-1, m_block=-1, waves=-1, kw=-1, splitk=-1, m_tiles=-1, slabs_per_wave=-1,
-                 ring_depth=-1):
-        super().__init__(family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth)
+                 ring_depth=-1, one_shot=-1):
+        super().__init__(family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot)
 
 
 # every symbol include/flute_amd.h declares: name -> (restype, argtypes)
@@ -76,7 +76,7 @@ def get() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.flute_abi_version() != 3:
+        if lib.flute_abi_version() != 4:
             raise ImportError("flute_amd: ABI version mismatch, rebuild libflute_amd.so")
         _lib = lib
     return _lib

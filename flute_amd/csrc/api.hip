@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "qgemm_decode.h"
 #include "qgemm_stream.h"
+#include "qgemm_oneshot.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
 #include "qgemm_block.h"
@@ -26,10 +27,10 @@ using namespace flute_amd;
 
 namespace {
 
-struct Ovr { int family, m_block, waves, kw, splitk, m_tiles, slabs, depth; };
+struct Ovr { int family, m_block, waves, kw, splitk, m_tiles, slabs, depth, one_shot; };
 Ovr ovr_of(const flute_overrides* o) {
-    if (!o) return Ovr{-1, -1, -1, -1, -1, -1, -1, -1};
-    return Ovr{o->family, o->m_block, o->waves, o->kw, o->splitk, o->m_tiles, o->slabs_per_wave, o->ring_depth};
+    if (!o) return Ovr{-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    return Ovr{o->family, o->m_block, o->waves, o->kw, o->splitk, o->m_tiles, o->slabs_per_wave, o->ring_depth, o->one_shot};
 }
 
 constexpr int kMaxLds = 160 * 1024;
@@ -136,6 +137,80 @@ bool stream_shape(int bits, int mb, int lg, int units, int krange, int G, bool s
     return true;
 }
 
+// ---- one-shot decode kernel (qgemm_oneshot.h): launch shape --------------------------------------------
+// A workgroup of W = upw x kw waves owns upw units for the whole of K (no persistence, no grid K split): wave
+// (ul, kpart) decodes pk <= D pieces of its unit.  Candidates: D pieces per wave x W in {4, 8, 16}, kw the
+// smallest power of two that fits K into kw x D pieces.  Ranked by what tools/ubench/oneshot_lab measured on
+// 4096^2 / 4096x11008 (profiles/r03_oneshot_lab.jsonl): launches that give every CU a workgroup first, then
+// the smallest in-workgroup K split (kw = 1 needs no cross-wave reduction), then the smallest workgroup that
+// keeps the launch at <= 3 workgroups per CU (every workgroup builds its own table image).
+// Template knobs: Stages 2..5 -> rank 0..3; QuantMapMode digit (4-bit ids) 1 / 2 -> D = 4 / 8 only.
+struct OneShape { int W, kw, upw, pk, depth, pipe, ipw, grid; size_t lds; };
+struct OneArgs { int lg, lkw, upw, pk, ipw, depth, pipe; };
+
+int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t, int template_id,
+                 const Ovr& ov, flute_plan* p, OneArgs* oa) {
+    if (lg < 6) return FLUTE_ERR_SHAPE;                       // 32-wide groups: twice the scale words per wave
+    if ((K >> lg) & 1) return FLUTE_ERR_SHAPE;                // scale rows are read as aligned dwords (two groups each)
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int units = N / J;
+    const int npieces = ceil_div(K, 512);
+    int mb = 1; while (mb < M) mb <<= 1;
+    if (mb > 4 || (bits == 3 && mb > 2)) return FLUTE_ERR_SHAPE;
+    const int dlo = (bits == 3) ? 2 : 4, dhi = 2 * dlo;
+    int dsel = 0;                                             // 0: both depths
+    if (bits == 4 && (template_id % 4) == 1) dsel = dlo;
+    if (bits == 4 && (template_id % 4) == 2) dsel = dhi;
+    if (ov.one_shot == 1 && (ov.depth == dlo || ov.depth == dhi)) dsel = ov.depth;
+    const int wcap = std::min(t.threads, oneshot_max_threads(bits, mb)) / 64;
+    const int runs = oneshot_lut_runs(bits);
+    const int xpr = (mb == 4) ? 1 : 2;
+    std::vector<OneShape> cands;
+    for (int D = dhi; D >= dlo; D /= 2) {
+        if (dsel && D != dsel) continue;
+        for (int W = 4; W <= 16; W *= 2) {
+            int w = W;
+            if (ov.waves > 0) { if (W != 4) continue; w = ov.waves; }
+            if (w > wcap || w < 1) continue;
+            int kw = 1;
+            while (ceil_div(npieces, kw) > D) kw *= 2;
+            if (ov.kw > 0) kw = floor_pow2(ov.kw);
+            if (kw > w || w % kw || ceil_div(npieces, kw) > D) continue;
+            OneShape s;
+            s.W = w; s.kw = kw; s.upw = w / kw; s.pk = ceil_div(npieces, kw); s.depth = D;
+            s.ipw = ceil_div(runs, w);
+            if (bits != 2 && s.ipw > 8) continue;             // a wave's table entries: one per lane
+            if (npieces * 64 > xpr * w * 64) continue;        // activations staged from registers only
+            s.grid = ceil_div(units, s.upw);
+            s.lds = oneshot_lds_bytes(bits, mb, D, lg, K, w);
+            if (s.lds > (size_t)kMaxLds) continue;
+            s.pipe = (bits == 4 && mb == 1 && s.pk == D && npieces == kw * s.pk && units % s.upw == 0) ? 1 : 0;
+            cands.push_back(s);
+        }
+    }
+    if (cands.empty()) return FLUTE_ERR_SHAPE;
+    auto fills = [&](const OneShape& s) { return (long)s.grid * 10 >= (long)num_sms * 9; };
+    std::stable_sort(cands.begin(), cands.end(), [&](const OneShape& a, const OneShape& b) {
+        if (fills(a) != fills(b)) return fills(a);
+        if (!fills(a)) return a.grid > b.grid;
+        if (a.kw != b.kw) return a.kw < b.kw;
+        const bool many_a = a.grid > 3 * num_sms, many_b = b.grid > 3 * num_sms;      // > 3 workgroups per CU: take the larger workgroup
+        if (many_a != many_b) return many_b;
+        if (a.W != b.W) return a.W < b.W;
+        return a.depth > b.depth;
+    });
+    size_t pick = std::min((size_t)std::max(0, t.stages - 2), cands.size() - 1);
+    if (ov.waves > 0 || ov.kw > 0) pick = 0;
+    const OneShape& s = cands[pick];
+    p->family = 0;
+    p->m_block = mb; p->waves = s.W; p->kw = s.kw; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)s.grid; p->block = (unsigned)(s.W * 64);
+    p->lds_bytes = s.lds; p->lut_copies = 32;
+    p->ring_depth = s.depth; p->visits = 1; p->k_chunks = 1; p->one_shot = 1 + s.pipe;
+    if (oa) { oa->lg = lg; oa->lkw = ilog2(s.kw); oa->upw = s.upw; oa->pk = s.pk; oa->ipw = s.ipw; oa->depth = s.depth; oa->pipe = s.pipe; }
+    return FLUTE_OK;
+}
+
 int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
                 const Ovr& ov, size_t workspace_bytes, flute_plan* p, StreamArgs* sa) {
     const int J = (bits == 3) ? 16 : 16 / bits;
@@ -204,14 +279,7 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     p->lds_bytes = s.total;
     p->lut_copies = 32;
     p->ring_depth = depth; p->visits = s.visits; p->k_chunks = s.nchunks;
-    {   // one-shot variant: single visit, no K chunks, every wave's pieces fit the prologue's D requests
-        const int one_depth = (bits == 3) ? 2 : 4;
-        const int pk = ceil_div(ceil_div(krange, 512), s.kw);
-        const bool one = s.visits == 1 && s.nchunks == 1 && pk <= one_depth &&
-                         s.W * 64 <= stream_max_threads(bits, mb, one_depth) && ov.depth <= 0;
-        p->one_shot = one ? 1 : 0;
-        if (one) p->ring_depth = one_depth;
-    }
+    p->one_shot = 0;
     if (sa) {
         memset(sa, 0, sizeof(*sa));
         sa->M = M; sa->N = N; sa->K = K; sa->G = G; sa->lg = lg;
@@ -275,7 +343,7 @@ int plan_legacy_decode(int bits, int lg, int M, int N, int K, int num_sms, const
 
 int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
-              StreamArgs* sa) {
+              StreamArgs* sa, OneArgs* oa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
     if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
     if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
@@ -356,7 +424,26 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
 
     int rc = FLUTE_OK;
     if (family == 0) {
-        rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
+        // Two decode kernels: the one-shot kernel (qgemm_oneshot.h: non-persistent workgroups, every request up
+        // front) and the persistent ring kernel (qgemm_stream.h).  Forced by override (one_shot 1 / 0; an explicit
+        // ring depth or grid K split means the ring kernel) or by the template (4-bit QuantMapMode digit 1, 2:
+        // one-shot with 4 / 8 pieces per wave, 3: ring; 2- / 3-bit SMs_Multiple 4: one-shot, 2: ring); automatic:
+        // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup.
+        int want = ov.one_shot;
+        if (want < 0 && (ov.depth > 0 || ov.splitk > 1)) want = 0;
+        if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
+        if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
+        bool taken = false;
+        if (want != 0) {
+            flute_plan q;
+            memset(&q, 0, sizeof(q));
+            if (plan_oneshot(bits, lg, M, N, K, num_sms, t, template_id, ov, &q, oa) == FLUTE_OK &&
+                (want == 1 || ((size_t)N * K <= ((size_t)64 << 20) && (long)q.grid * 2 >= (long)num_sms))) {
+                *p = q;
+                taken = true;
+            }
+        }
+        if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
@@ -473,11 +560,11 @@ struct PlanKey {
     Ovr ov;
     bool operator==(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) == 0; }
 };
-struct PlanEntry { PlanKey key; int rc; flute_plan plan; flute_template_info tinfo; StreamArgs sa; bool valid; };
+struct PlanEntry { PlanKey key; int rc; flute_plan plan; flute_template_info tinfo; StreamArgs sa; OneArgs oa; bool valid; };
 
 int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
-              StreamArgs* sa) {
+              StreamArgs* sa, OneArgs* oa) {
     constexpr int kEntries = 32;
     thread_local PlanEntry cache[kEntries] = {};
     thread_local int next = 0;
@@ -488,7 +575,7 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     for (int i = 0; i < kEntries; ++i) {
         const PlanEntry& e = cache[i];
         if (e.valid && e.key == key) {
-            if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; }
+            if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; if (oa) *oa = e.oa; }
             return e.rc;
         }
     }
@@ -498,10 +585,11 @@ int make_plan(int dtype, int bits, int group, int M, int N, int K, int template_
     e.key = key;
     memset(&e.plan, 0, sizeof(e.plan));
     memset(&e.sa, 0, sizeof(e.sa));
+    memset(&e.oa, 0, sizeof(e.oa));
     e.rc = make_plan_uncached(dtype, bits, group, M, N, K, template_id, num_sms, workspace_bytes, ov, &e.plan, &e.tinfo,
-                              &e.sa);
+                              &e.sa, &e.oa);
     e.valid = true;
-    if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; }
+    if (e.rc == FLUTE_OK) { *p = e.plan; if (tinfo) *tinfo = e.tinfo; if (sa) *sa = e.sa; if (oa) *oa = e.oa; }
     return e.rc;
 }
 
@@ -563,7 +651,7 @@ const char* flute_strerror(int status) {
         case FLUTE_ERR_TEMPLATE_ID: return "Unsupported template_id value";
         case FLUTE_ERR_SHAPE: return "Unsupported shape: need N % (16/num_bits*TileP) == 0 (N % 512 for 3 bits), K % 64 == 0, K % group_size == 0";
         case FLUTE_ERR_WORKSPACE: return "workspace too small";
-        case FLUTE_ERR_LAUNCH: return "HIP error: kernel launch failed (invalid argument)";
+        case FLUTE_ERR_LAUNCH: return "CUDA error: invalid argument (HIP kernel launch failed)";   // flute/tune.py:160 string-matches this prefix
         case FLUTE_ERR_DTYPE: return "Unsupported dtype (fp16 / bf16 only)";
         case FLUTE_ERR_HADAMARD_SIZE: return "Only power of two Hadamard sizes up to 2^15 are supported";
         case FLUTE_ERR_NULL: return "null pointer argument";
@@ -587,7 +675,7 @@ int flute_qgemm_plan_ex(int dtype, int num_bits, int group_size, int M, int N, i
                         int num_sms, size_t workspace_bytes, const flute_overrides* ovr, flute_plan* out) {
     if (!out) return FLUTE_ERR_NULL;
     return make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
-                     ovr_of(ovr), out, nullptr, nullptr);
+                     ovr_of(ovr), out, nullptr, nullptr, nullptr);
 }
 
 int flute_qgemm_plan(int dtype, int num_bits, int group_size, int M, int N, int K,
@@ -610,6 +698,9 @@ static Ovr hadamard_ovr(Ovr o, int hadamard_size, int bits, int M, int N, int K)
     if (hadamard_size > 1 && hadamard_size <= 512 && o.family < 0 && M >= 3 && M <= 4 &&
         (size_t)N * K <= ((size_t)32 << 20))
         o.family = 0;
+    // the fused rotation is done by the workgroup's waves, 512 k each: 8 waves rotate a 4096-k row in one pass
+    // (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with the 4-wave shape the plain product prefers)
+    if (hadamard_size > 1 && hadamard_size <= 512 && M <= 4 && o.waves < 0 && o.kw < 0 && o.one_shot != 0) o.waves = 8;
     return o;
 }
 
@@ -617,7 +708,7 @@ int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hada
                                int N, int K, int template_id, int num_sms, size_t workspace_bytes) {
     flute_plan p;
     if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
-                  hadamard_ovr(ovr_of(nullptr), hadamard_size, num_bits, M, N, K), &p, nullptr, nullptr))
+                  hadamard_ovr(ovr_of(nullptr), hadamard_size, num_bits, M, N, K), &p, nullptr, nullptr, nullptr))
         return 0;
     return hadamard_fusable(p, hadamard_size, K) ? 1 : 0;
 }
@@ -641,9 +732,10 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     flute_plan p;
     flute_template_info t;
     StreamArgs sa;
+    OneArgs oa;
     if (!workspace) workspace_bytes = 0;
     const int rc = make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
-                             hadamard_ovr(ovr_of(ovr), hadamard_size, num_bits, M, N, K), &p, &t, &sa);
+                             hadamard_ovr(ovr_of(ovr), hadamard_size, num_bits, M, N, K), &p, &t, &sa, &oa);
     if (rc) return rc;
     if (P != num_bits * (N / 16)) return FLUTE_ERR_SHAPE;
     if (!A || !Q || !D || !S || !QM2) return FLUTE_ERR_NULL;
@@ -664,12 +756,39 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
     const float had_scale = 1.0f / sqrtf((float)(1 << had_log));     // as flute_hadamard: bit-identical results
 
+    if (p.family == 0 && p.one_shot) {
+        OneKernel fn = nullptr;
+        const int had = had_log > 0 ? 1 : 0;
+        if (num_bits == 4) fn = dtype == 0 ? oneshot_kernel_b4_f16(t.tile_p, p.m_block, oa.depth, had, oa.pipe)
+                                           : oneshot_kernel_b4_bf16(t.tile_p, p.m_block, oa.depth, had, oa.pipe);
+        else if (num_bits == 2) fn = dtype == 0 ? oneshot_kernel_b2_f16(t.tile_p, p.m_block, oa.depth, had, 0)
+                                                : oneshot_kernel_b2_bf16(t.tile_p, p.m_block, oa.depth, had, 0);
+        else fn = oneshot_kernel_b3(dtype, t.tile_p, p.m_block, oa.depth, had);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        uint32_t geo = OneGeo::pack(oa.lg, oa.lkw, oa.upw, oa.pk, oa.ipw, had_log);
+        float hs = had_scale;
+        uint64_t* stamps = nullptr;
+#ifdef FLUTE_STAMPS
+        if (workspace && workspace_bytes >= (size_t)p.grid * p.waves * 128) stamps = reinterpret_cast<uint64_t*>(workspace);
+#endif
+        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D, &hs, &stamps};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
+
     if (p.family == 0) {
         sa.A = A; sa.Q = reinterpret_cast<const uint32_t*>(Q); sa.D = D; sa.S = S;
         sa.QM2 = reinterpret_cast<const uint32_t*>(QM2);
         sa.partial = reinterpret_cast<float*>(workspace);
         sa.had_log = had_log; sa.had_scale = had_scale; sa.m0 = 0;
-        StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth, p.one_shot);
+        StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth, 0);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&sa};

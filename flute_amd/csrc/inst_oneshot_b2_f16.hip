@@ -1,0 +1,18 @@
+// Explicit instantiations of the one-shot decode kernel (qgemm_oneshot.h), num_bits = 2, F16: TileP x rows per
+// pass x pieces per wave x fused Hadamard (+ the software-pipelined 4-bit single-row loop).  Built with
+// -mllvm -amdgpu-kernarg-preload-count=14 (Makefile): the leading kernel arguments arrive in SGPRs.
+#include "kernels.h"
+#include "qgemm_oneshot.h"
+namespace flute_amd {
+#define FLUTE_ONE(TP, MB, D, H, O) (OneKernel)qgemv_oneshot_kernel<F16, 2, TP, MB, D, (MB == 4 ? 1 : 2), H, O>
+#define FLUTE_ROW(TP, MB, D) \
+    if (tile_p == TP && mb == MB && depth == D) return had ? FLUTE_ONE(TP, MB, D, true, 1) : FLUTE_ONE(TP, MB, D, false, 1);
+#define FLUTE_ROW_PIPE(TP, D) \
+    if (tile_p == TP && mb == 1 && depth == D && pipe) return had ? FLUTE_ONE(TP, 1, D, true, 17) : FLUTE_ONE(TP, 1, D, false, 17);
+OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe) {
+    (void)pipe;
+    FLUTE_ROW(32, 1, 4) FLUTE_ROW(32, 1, 8) FLUTE_ROW(32, 2, 4) FLUTE_ROW(32, 2, 8) FLUTE_ROW(32, 4, 4) FLUTE_ROW(32, 4, 8)
+    FLUTE_ROW(64, 1, 4) FLUTE_ROW(64, 1, 8) FLUTE_ROW(64, 2, 4) FLUTE_ROW(64, 2, 8) FLUTE_ROW(64, 4, 4) FLUTE_ROW(64, 4, 8)
+    return nullptr;
+}
+}  // namespace flute_amd

@@ -17,6 +17,14 @@ typedef void (*StreamKernel)(const StreamArgs);
 StreamKernel stream_kernel_b4(int dtype, int tile_p, int mb, int depth, int one_shot);
 StreamKernel stream_kernel_b3(int dtype, int tile_p, int mb, int depth, int one_shot);
 StreamKernel stream_kernel_b2(int dtype, int tile_p, int mb, int depth, int one_shot);
+// one-shot decode kernel (qgemm_oneshot.h): mb rows per pass (1/2/4; b=3: 1/2), depth = pieces per wave (4/8; b=3: 2/4), had = fused
+// Hadamard pre-rotation, pipe = software-pipelined half-piece loop (4-bit, one row, every wave with `depth` pieces)
+typedef void (*OneKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, uint64_t*);
+OneKernel oneshot_kernel_b4_f16(int tile_p, int mb, int depth, int had, int pipe);
+OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pipe);
+OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
+OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
+OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had);
 // block-tiled prefill kernel (qgemm_block.h): cfg 0 = 256 x 256 block, cfg 1 = 128 x 256
 struct BlockArgs;
 typedef void (*BlockKernel)(const BlockArgs);

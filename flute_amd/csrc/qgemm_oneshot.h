@@ -1,0 +1,505 @@
+// Latency-bound decode launches (round 3): one visit per workgroup, every wave's whole K slice requested by
+// the prologue - the headline regime (M = 1, 4096 x 4096: 8.9 MB in one launch of ~4 us, of which the HBM
+// stream is < 1.5 us).  Replaces the one-shot instantiations of qgemm_stream.h; same arithmetic, same table /
+// lookup scheme, same wire format.  Reference: qgemm_device's prologue + main loop
+// (flute/csrc/qgemm_kernel.hpp:546-557 table staging, :617-712 loop) for M <= 4.
+//
+// What the round-2 stamps showed and what this kernel does about it (profiles/r02_stamps_decode.json,
+// profiles/r03_oneshot_lab*.jsonl):
+//   * kernel arguments arrived by s_load (a scalar-cache miss) before anything could be requested.  Here the
+//     first 14 argument dwords are PRELOADED into SGPRs by the dispatcher (-mllvm
+//     -amdgpu-kernarg-preload-count: the four source pointers, K, N, the packed launch geometry, M, D).
+//   * a CU's texture addresser takes ~16 cycles per wave-wide memory instruction, whatever its width: with
+//     8 waves x 9 requests the LAST weight request left the CU ~1000 cycles after the wave started.  Here a
+//     wave issues 1 table + XPR activation + NSL scale + D weight requests (7 for the headline).
+//   * every wave waited for ALL of its weights and its (youngest, HBM-cold) scale block before the first
+//     lookup.  Here the scale words are requested BEFORE the weights, each piece is released by its own
+//     counted vmcnt, and (PIPE) the lookups of half-piece h+1 are in flight while half-piece h is multiplied.
+//   * the table image was written with 8-way bank conflicts; here a wave writes whole 1-KiB runs (8 entries x
+//     128 B, lane l -> 16-B piece l of the run), the entry word fetched from the lane that loaded it by
+//     ds_bpermute.
+//   * scale staging: one aligned dword (two groups) per lane into a wave-private [group][column] image (G must be
+//     even: a buffer_load_dword of an odd element index returns the aligned-down dword - measured; odd G takes
+//     the ring kernel); a piece reads its J scales with ONE vector read.
+// LDS: [table image][activations MB x KX][per-wave scale images][arrival counters + K-split partials].
+#pragma once
+#include "qgemm_stream.h"
+
+namespace flute_amd {
+
+// launch geometry packed into one kernel-argument dword (preloaded)
+struct OneGeo {
+    static constexpr uint32_t pack(int lg, int lkw, int upw, int pk, int ipw, int had_log) {
+        return (uint32_t)lg | ((uint32_t)lkw << 4) | ((uint32_t)upw << 8) | ((uint32_t)pk << 13) |
+               ((uint32_t)ipw << 17) | ((uint32_t)had_log << 24);
+    }
+};
+
+__host__ __device__ constexpr int oneshot_max_threads(int bits, int mb) {
+    return (bits == 3 || (bits == 2 && mb == 4)) ? 512 : 1024;
+}
+// table image: bytes, 1-KiB write runs
+__host__ __device__ constexpr int oneshot_lut_bytes(int bits) { return bits == 3 ? 64 * 128 : 65536; }
+__host__ __device__ constexpr int oneshot_lut_runs(int bits) { return bits == 4 ? 32 : (bits == 3 ? 8 : 64); }
+// dwords of scales a wave stages: J columns x D pieces x (512 >> lg) groups / 2; loads per lane for g >= 64
+__host__ __device__ constexpr int oneshot_scale_loads(int bits, int depth) {
+    return ((bits == 3 ? 16 : 16 / bits) * depth * 8 / 2 + 63) / 64;
+}
+// dynamic LDS of a launch (the kernel carves with the same formulas)
+__host__ __device__ constexpr size_t oneshot_lds_bytes(int bits, int mb, int depth, int lg, int K, int waves) {
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    return (size_t)oneshot_lut_bytes(bits) + (size_t)mb * ((K + 511) / 512 * 512) * 2 +
+           (size_t)waves * J * depth * (512 >> lg) * 2 + 128 + (size_t)waves * J * mb * 4;
+}
+
+__device__ __forceinline__ uint32_t buf_load4_at(uint32_t voff, srd_t srd, uint32_t soff) {
+    uint32_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    return v;
+}
+__device__ __forceinline__ ring16_t buf_load16_nt(uint32_t voff, srd_t srd, uint32_t soff) {
+    ring16_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    return v;
+}
+// hidden LDS reads of the pipelined piece loop (released by the counted lgkmcnt of the lookups behind them)
+__device__ __forceinline__ ring16_t lds_hidden128(uint32_t addr) {
+    ring16_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x2_t lds_hidden64(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// OPT bits (development / A-B measurements, tools/ubench/oneshot_lab.hip): 1 = nt on the weight loads,
+// 2 = ablate the lookups (timing floor: stream + prologue only), 8 = wait for every piece before the first
+// lookup (round-2 behaviour), 16 = software-pipelined half-piece loop (4-bit, one row, every wave with D pieces)
+template <typename T, int BITS, int TILEP, int MB, int D, int XPR, bool HAD = false, int OPT = 0>
+__global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_kernel(
+    const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
+    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp, float had_scale,
+    uint64_t* __restrict__ stamps) {
+    using L = Layout<BITS>;
+    using NT = Num<T>;
+    constexpr int J = L::J;
+    constexpr int NP = L::NPLANES;
+    constexpr int LJ = (BITS == 4) ? 2 : (BITS == 2 ? 3 : 4);      // log2(J)
+    constexpr int NSL = oneshot_scale_loads(BITS, D);
+    constexpr int LUT = oneshot_lut_bytes(BITS);
+    constexpr int ESTRIDE = (BITS == 3) ? 128 : 256;
+    constexpr bool PIPE = (OPT & 16) && BITS == 4 && MB == 1;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();                  // v_perm-built table addresses are absolute
+#ifdef FLUTE_STAMPS
+    uint64_t stamp[16];
+    for (int i = 0; i < 16; ++i) stamp[i] = 0;
+    stamp[0] = wall_clock64();                                    // 100 MHz, chip-wide: start skew / end
+    stamp[1] = __builtin_amdgcn_s_memtime();                       // shader cycles: the phases of this wave
+#define FLUTE_OSTAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FLUTE_OSTAMP(i)
+#endif
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = geo & 15, lkw = (geo >> 4) & 15, upw = (geo >> 8) & 31, pk = (geo >> 13) & 15;
+    const int ipw = (geo >> 17) & 127, had_log = (geo >> 24) & 15;
+    const int kw = 1 << lkw;
+    const int nthr = (upw << lkw) * 64;                            // == blockDim.x (an implicit argument: a scalar load away)
+    const int ul = wave >> lkw;
+    const int kpart = wave & (kw - 1);
+    const int units = N >> LJ;
+    const int G = K >> lg;
+    const int unit = blockIdx.x * upw + ul;
+    const bool live = unit < units;
+    const int urow = min(unit, units - 1);
+    const int npieces = (K + 511) >> 9;
+    const int p0 = kpart * pk;
+    const int np = live ? max(0, min(pk, npieces - p0)) : 0;
+    const int KX = npieces << 9;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t row_bytes = (uint32_t)K * 2u;
+
+    // LDS carve (oneshot_lds_bytes)
+    const int gpp = 512 >> lg;                                     // groups per piece
+    const int ngm = D * gpp;                                       // groups per wave image
+    const uint32_t x_off = LUT;
+    const uint32_t s_off = x_off + (uint32_t)(MB * KX * 2);
+    const uint32_t s_wave_bytes = (uint32_t)(J * ngm * 2);
+    const uint32_t sbase = s_off + (uint32_t)wave * s_wave_bytes;
+    const uint32_t red_off = s_off + (uint32_t)(nthr >> 6) * s_wave_bytes;
+
+    // ---- requests, oldest first: table word, activations, scale words, then the weights ----
+    // table: wave w writes runs [w * ipw, min(RUNS, (w + 1) * ipw)) of the image; b = 4 / 3: a run is 8 entries
+    // x 128 B and the wave's (<= 64) entries are loaded one per lane; b = 2: the 16 source words, one per lane
+    const srd_t lut_srd = make_srd(QM2, (uint32_t)(4 << (2 * BITS)));
+    const int run0 = wave * ipw;
+    uint32_t lut_v;
+    if constexpr (BITS == 2) lut_v = buf_load4((uint32_t)(lane & 15) * 4u, lut_srd);
+    else lut_v = buf_load4((uint32_t)(run0 * 8 + lane) * 4u, lut_srd);
+
+    const srd_t x_srd = make_srd(Ap, (uint32_t)min((size_t)M * K * 2, (size_t)0xfffffff0u));
+    const int xrow_pieces = KX >> 3;
+    ring16_t xv[MB][XPR];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) {
+            const int pidx = r * nthr + tid;
+            const int k = pidx * 8;
+            const uint32_t vo = (pidx < xrow_pieces && k < K) ? (uint32_t)(((size_t)min(m, M - 1) * K + k) * 2) : 0x80000000u;
+            xv[m][r] = buf_load16(vo, x_srd, 0);
+        }
+
+    // scale words: lane q = lane + 64 r holds groups (2 gp, 2 gp + 1) of column j of this wave's K range,
+    // q = j * (ngm / 2) + gp.  G is even (host), so every word is an aligned dword; words past the row / past the
+    // wave's range read as zero.
+    const int col0 = unit_col0<BITS, TILEP>(urow);
+    const int g0 = (p0 * 512) >> lg;
+    const int lgh = 31 - __builtin_clz((unsigned)ngm) - 1;          // log2(ngm / 2)
+    const srd_t s_srd = make_srd(Sp, (uint32_t)min((size_t)N * G * 2, (size_t)0xfffffff0u));
+    uint32_t sv[NSL];
+    uint32_t s_keep[NSL];
+#pragma unroll
+    for (int r = 0; r < NSL; ++r) {
+        const int q = lane + 64 * r;
+        const int j = q >> lgh;
+        const int gp = q & ((1 << lgh) - 1);
+        const int gi = g0 + 2 * gp;
+        const bool mine = live && j < J && gi < G && 2 * gp < np * gpp;
+        s_keep[r] = !mine ? 0u : (gi + 1 < G ? 0xffffffffu : 0x0000ffffu);
+        sv[r] = buf_load4_at(mine ? (uint32_t)(((size_t)(col0 + j * TILEP) * G + gi) * 2) : 0x80000000u, s_srd, 0);
+    }
+
+    // weights: piece i of plane pl -> q[i][pl]; positions in the VECTOR offset (the only offset the range check
+    // covers): pieces past np and bytes past the end of a ragged row read as zero
+    srd_t qsrd[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+        qsrd[pl] = make_srd(reinterpret_cast<const char*>(Qp) + (size_t)unit_row<BITS, TILEP>(urow, pl, N) * row_bytes,
+                            live ? row_bytes : 0u);
+    ring16_t q[D][NP];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const uint32_t vo = lane16 + ((i < np) ? (uint32_t)(p0 + i) * 1024u : 0x80000000u);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if constexpr (OPT & 1) q[i][pl] = buf_load16_nt(vo, qsrd[pl], 0);
+            else q[i][pl] = buf_load16(vo, qsrd[pl], 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FLUTE_OSTAMP(2);
+
+    // ---- table image: bpermutes in batches of four ahead of their writes ----
+    constexpr int NX = MB * XPR;
+    vm_wait_regs<NX + NSL + D * NP>(lut_v);
+    FLUTE_OSTAMP(3);
+    {
+        constexpr int RUNS = oneshot_lut_runs(BITS);
+        const int nrun = max(0, min(ipw, RUNS - run0));
+        for (int i0 = 0; i0 < nrun; i0 += 4) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (BITS == 2) {
+                    const int e = (run0 + i0 + u) * 4 + (lane >> 4);
+                    lo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((e & 15) * 4, (int)lut_v);
+                    hi[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, (int)lut_v);
+                } else {
+                    lo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((((i0 + u) * 8 + (lane >> 3)) & 63) * 4, (int)lut_v);
+                    hi[u] = lo[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u < nrun) {
+                    uint32_t addr;
+                    if constexpr (BITS == 2) addr = (uint32_t)(run0 + i0 + u) * 1024u + lane16;
+                    else addr = (uint32_t)((run0 + i0 + u) * 8 + (lane >> 3)) * ESTRIDE + (uint32_t)(lane & 7) * 16u;
+                    *reinterpret_cast<uint4*>(smem + addr) = make_uint4(lo[u], hi[u], lo[u], hi[u]);
+                }
+            }
+        }
+    }
+    int* arrive = reinterpret_cast<int*>(smem + red_off);
+    if (kw > 1 && tid < upw) arrive[tid] = 0;
+    FLUTE_OSTAMP(4);
+
+    // ---- activations -> LDS [MB][KX] (zero beyond K); fused pre-rotation: the 64 pieces a wave stages are 512
+    // consecutive k of one row = whole Hadamard blocks (K % had == 0, had <= 512; qgemm.cpp:201-244) ----
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + x_off);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) vm_wait_regs<NSL + D * NP>(xv[m][r]);
+    FLUTE_OSTAMP(5);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) {
+            const int pidx = r * nthr + tid;
+            if (pidx < xrow_pieces) {                              // wave-uniform: rows are whole 512-k spans
+                uint32_t w[4] = {xv[m][r].x, xv[m][r].y, xv[m][r].z, xv[m][r].w};
+                if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
+                const bool inside = pidx * 8 < K;
+                *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
+                    inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        const uint16_t* A = reinterpret_cast<const uint16_t*>(Ap);
+        for (int pidx = XPR * nthr + tid; pidx < xrow_pieces; pidx += nthr) {     // rows longer than XPR x threads pieces
+            const int k = min(pidx * 8, K - 8);
+            const uint4 t = *reinterpret_cast<const uint4*>(A + (size_t)min(m, M - 1) * K + k);
+            uint32_t w[4] = {t.x, t.y, t.z, t.w};
+            if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
+            const bool inside = pidx * 8 < K;
+            *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
+                inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    FLUTE_OSTAMP(6);
+    __syncthreads();                                               // table / activations visible to every wave
+    FLUTE_OSTAMP(7);
+
+    // ---- scale image [group][column] (wave-private: no barrier) ----
+#pragma unroll
+    for (int r = 0; r < NSL; ++r) {
+        vm_wait_regs<D * NP>(sv[r]);
+        const int qq = lane + 64 * r;
+        const int j = qq >> lgh;
+        const int gp = qq & ((1 << lgh) - 1);
+        if (j < J) {
+            const uint32_t w = sv[r] & s_keep[r];
+            uint16_t* img = reinterpret_cast<uint16_t*>(smem + sbase) + (size_t)(2 * gp) * J + j;
+            img[0] = (uint16_t)(w & 0xffffu);
+            img[J] = (uint16_t)(w >> 16);
+        }
+    }
+    FLUTE_OSTAMP(8);
+
+    // per-lane constants of the piece loop
+    const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
+    const int gl = (8 * lane) >> lg;                               // group of the lane's 8 k inside a piece
+    const uint32_t s_lane = sbase + (uint32_t)(gl * J) * 2u;
+    const uint32_t x_lane = x_off + lane16 + (uint32_t)p0 * 1024u;
+
+    float acc[J][MB];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+
+    auto compute_piece = [&](auto slot_tag) {
+        constexpr int i = decltype(slot_tag)::value;
+        const uint32_t xa = x_lane + (uint32_t)i * 1024u;
+        const uint32_t sa = s_lane + (uint32_t)(i * gpp * J) * 2u;
+        uint32_t xw[MB][4];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const uint4 t = lds_ld128(xa + (uint32_t)(m * KX * 2));
+            xw[m][0] = t.x; xw[m][1] = t.y; xw[m][2] = t.z; xw[m][3] = t.w;
+        }
+        uint32_t scw[J / 2];                                       // J scales: one vector read (J = 4: 8 B)
+        if constexpr (J == 4) { const uint2 t = lds_ld64(sa); scw[0] = t.x; scw[1] = t.y; }
+        else {
+#pragma unroll
+            for (int c = 0; c < J / 8; ++c) {
+                const uint4 t = lds_ld128(sa + 16u * c);
+                scw[4 * c] = t.x; scw[4 * c + 1] = t.y; scw[4 * c + 2] = t.z; scw[4 * c + 3] = t.w;
+            }
+        }
+        float al[J][MB];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) al[j][m] = 0.f;
+        if constexpr (OPT & 2) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[ww % J][m] += __builtin_bit_cast(float, q[i][pl][ww] ^ xw[m][ww]);
+        } else if constexpr (BITS == 2) {
+#pragma unroll
+            for (int hw = 0; hw < 4; hw += 2) {         // two batches of 8 byte lookups (2 columns each)
+                u32x2_t v[8];
+#pragma unroll
+                for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp)
+                        v[ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[i][0][hw + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
+                lds_lookup_wait8(v);
+#pragma unroll
+                for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            al[2 * jp][m] = NT::dot2(v[ww * 4 + jp].x, xw[m][hw + ww], al[2 * jp][m]);
+                            al[2 * jp + 1][m] = NT::dot2(v[ww * 4 + jp].y, xw[m][hw + ww], al[2 * jp + 1][m]);
+                        }
+            }
+        } else if constexpr (BITS == 4) {
+            uint32_t v[16];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[i][0][ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
+            lds_lookup_wait(v);
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[ww * 4 + j], xw[m][ww], al[j][m]);
+        } else {
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {            // one k-pair position: 16 fields in three planes
+                const uint32_t w[3] = {q[i][0][ww], q[i][1][ww], q[i][2][ww]};
+                uint32_t v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = lds_lookup32((field<3>(w, j) << 7) | lane_off);
+                lds_lookup_wait(v);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[j], xw[m][ww], al[j][m]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float sf = scale_to_float<T>((j & 1) ? (scw[j / 2] >> 16) : (scw[j / 2] & 0xffffu));
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[j][m] = __builtin_fmaf(al[j][m], sf, acc[j][m]);
+        }
+    };
+
+    if constexpr (PIPE) {
+        // Software-pipelined loop over half pieces (8 lookups each).  The host launches this variant only when
+        // EVERY wave of the grid holds exactly D pieces (api.hip: plan_oneshot; a run-time fallback to the plain
+        // loop would put two sets of counted waits on the same in-flight registers behind a branch, the
+        // arrangement hipcc mis-schedules - measured: wrong results).  The lookups of half h+1 - and, on a piece
+        // boundary, its activation / scale reads - are issued before the multiplies of half h; LDS returns in
+        // order, so "at most 8 younger operations outstanding" releases half h.
+        {
+            uint32_t v[2][8];
+            ring16_t xq[2];
+            u32x2_t sq[2];
+            float al[J];
+            auto issue_half = [&](auto h_tag) {
+                constexpr int h = decltype(h_tag)::value;
+                constexpr int I = h / 2, HF = h % 2;
+                if constexpr (HF == 0) {
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[I][0]) : "n"((OPT & 8) ? 0 : (D - 1 - I)) : "memory");
+                    xq[I & 1] = lds_hidden128(x_lane + (uint32_t)I * 1024u);
+                    sq[I & 1] = lds_hidden64(s_lane + (uint32_t)(I * gpp * J) * 2u);
+                }
+#pragma unroll
+                for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[h & 1][ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[I][0][2 * HF + ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
+            };
+            issue_half(std::integral_constant<int, 0>{});
+            [&]<int... H>(std::integer_sequence<int, H...>) {
+                ([&] {
+                    constexpr int I = H / 2, HF = H % 2;
+                    if constexpr (H + 1 < 2 * D) issue_half(std::integral_constant<int, H + 1>{});
+                    constexpr int YOUNGER = (H + 1 < 2 * D) ? 8 : 0;
+                    asm volatile("s_waitcnt lgkmcnt(%10)"
+                                 : "+v"(v[H & 1][0]), "+v"(v[H & 1][1]), "+v"(v[H & 1][2]), "+v"(v[H & 1][3]), "+v"(v[H & 1][4]),
+                                   "+v"(v[H & 1][5]), "+v"(v[H & 1][6]), "+v"(v[H & 1][7]), "+v"(xq[I & 1]), "+v"(sq[I & 1])
+                                 : "n"(YOUNGER) : "memory");
+                    if constexpr (HF == 0) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) al[j] = 0.f;
+                    }
+#pragma unroll
+                    for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) al[j] = NT::dot2(v[H & 1][ww * 4 + j], xq[I & 1][2 * HF + ww], al[j]);
+                    if constexpr (HF == 1) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            const uint32_t w = sq[I & 1][j / 2];
+                            acc[j][0] = __builtin_fmaf(al[j], scale_to_float<T>((j & 1) ? (w >> 16) : (w & 0xffffu)), acc[j][0]);
+                        }
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, 2 * D>{});
+        }
+    } else {
+        // ---- pieces, each released by its own counted wait (loads return in order) ----
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int YOUNGER = (OPT & 8) ? 0 : (D - 1 - I) * NP;
+                if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[I][0]) : "n"(YOUNGER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(q[I][0]), "+v"(q[I][1]), "+v"(q[I][2]) : "n"(YOUNGER) : "memory");
+                if (I < np) compute_piece(std::integral_constant<int, I>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, D>{});
+    }
+    FLUTE_OSTAMP(9);
+
+    // ---- lanes -> wave (DPP) -> [K split: waves -> LDS -> last arriver] -> output ----
+    uint16_t* Dout = reinterpret_cast<uint16_t*>(Dp);
+    auto store_out = [&](int j, int m, float v) {
+        if (m < M && live) Dout[(size_t)m * N + col0 + j * TILEP] = NT::from_float(v);
+    };
+    float tot[J][MB];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) tot[j][m] = wave_sum64(acc[j][m]);
+    FLUTE_OSTAMP(10);
+    if (kw == 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < J; ++j) store_out(j, m, tot[j][m]);
+        }
+    } else {
+        // no barrier: every wave leaves its partial sums and an arrival tick in LDS, the last arriver sums and
+        // stores (release on the tick / acquire by the reader: the partials are ordered before it)
+        float* rb = reinterpret_cast<float*>(smem + red_off) + 32;
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) rb[wave * (J * MB) + j * MB + m] = tot[j][m];
+        }
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == kw - 1) {
+            for (int t = lane; t < J * MB; t += 64) {
+                float sum = 0.f;
+                for (int kp = 0; kp < kw; ++kp) sum += rb[(ul * kw + kp) * (J * MB) + t];
+                store_out(t / MB, t % MB, sum);
+            }
+        }
+    }
+#ifdef FLUTE_STAMPS
+    FLUTE_OSTAMP(11);
+    __builtin_amdgcn_s_waitcnt(0);
+    stamp[12] = __builtin_amdgcn_s_memtime();
+    stamp[13] = wall_clock64();
+    if (lane == 0 && stamps != nullptr) {
+        uint64_t* o = stamps + ((size_t)blockIdx.x * (nthr >> 6) + wave) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef FLUTE_OSTAMP
+}
+
+}  // namespace flute_amd

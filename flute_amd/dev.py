@@ -49,9 +49,9 @@ def get_plan(M: int, N: int, K: int, num_bits: int, group_size: int, template_id
 
 
 def overrides_from_tuple(t) -> Optional[Overrides]:
-    """(family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave[, ring_depth]) -> Overrides; None when every
-    field is -1 (automatic plan)."""
-    t = tuple(int(v) for v in t) + (-1,) * (8 - len(t))
+    """(family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave[, ring_depth[, one_shot]]) -> Overrides; None
+    when every field is -1 (automatic plan)."""
+    t = tuple(int(v) for v in t) + (-1,) * (9 - len(t))
     if all(v == -1 for v in t):
         return None
     return Overrides(*t)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FLUTE_AMD_ABI_VERSION 3
+#define FLUTE_AMD_ABI_VERSION 4
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -34,7 +34,7 @@ enum flute_status {
     FLUTE_ERR_TEMPLATE_ID = -3,   /* "Unsupported template_id value" qgemm_kernel_raw_generated.cu:205 */
     FLUTE_ERR_SHAPE = -4,         /* shape / divisibility precondition (ops.py:40-49) */
     FLUTE_ERR_WORKSPACE = -5,     /* split-K needs more workspace than given */
-    FLUTE_ERR_LAUNCH = -6,        /* HIP launch failed ("CUDA error: invalid argument" analogue) */
+    FLUTE_ERR_LAUNCH = -6,        /* HIP launch failed: message starts "CUDA error: invalid argument" (tune.py:160) */
     FLUTE_ERR_DTYPE = -7,
     FLUTE_ERR_HADAMARD_SIZE = -8, /* hadamard_transform.cpp:23-25 */
     FLUTE_ERR_NULL = -9
@@ -82,7 +82,9 @@ typedef struct flute_plan {
     int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (2/4) */
     int visits;          /* decode: unit groups the busiest workgroup streams */
     int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
-    int one_shot;        /* decode: 1 = one-shot variant (single visit, all weight requests issued by the prologue) */
+    int one_shot;        /* decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
+                            non-persistent workgroups, every request issued by the prologue, ring_depth = pieces per
+                            wave), 2 = the same with the software-pipelined piece loop */
 } flute_plan;
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
@@ -96,10 +98,11 @@ typedef struct flute_plan {
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split
  *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
- *   ring_depth      decode: pieces in flight per wave (2/4); a given depth also selects the ring kernel
- *                   where the planner would take the one-shot variant */
+ *   ring_depth      decode: pieces in flight per wave (ring kernel 2/4; one-shot kernel 4/8, 3-bit 2/4); without
+ *                   one_shot = 1 a given depth selects the ring kernel
+ *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel */
 typedef struct flute_overrides {
-    int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth;
+    int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;
 
 /* D[M,N] = A[M,K] @ (table2-lookup(Q) * S)   fused LUT-dequant GEMM.

@@ -47,7 +47,7 @@ def test_error_messages_match_reference_prefixes():
     assert _lib.strerror(-3).startswith("Unsupported template_id value")
     assert _lib.strerror(-1).startswith("Unsupported num_bits value")
     assert _lib.strerror(-2).startswith("Unsupported group_size value")
-    assert "invalid argument" in _lib.strerror(-6)
+    assert _lib.strerror(-6).startswith("CUDA error: invalid argument")   # flute/tune.py:160
     with pytest.raises(RuntimeError, match="Unsupported template_id value"):
         _lib.check(-3)
 
@@ -110,8 +110,31 @@ def test_plan_families_and_invariants():
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches
     rc, p = plan(1, 28672, 8192)
     assert rc == 0 and p.family == 0 and p.waves == 14 and p.kw == 1 and p.visits == 2 and p.one_shot == 0
+    # layers up to 64 M weights: the one-shot kernel (qgemm_oneshot.h); 4096^2 has 8 pieces per unit row: a wave
+    # takes all 8 (no cross-wave reduction), every wave is full -> the software-pipelined loop (one_shot 2)
     rc, p = plan(1, 4096, 4096)
-    assert rc == 0 and p.family == 0 and p.one_shot == 1 and p.visits == 1 and p.waves % p.kw == 0
+    assert rc == 0 and p.family == 0 and p.one_shot == 2 and p.visits == 1 and p.waves % p.kw == 0
+    assert (p.waves, p.kw, p.ring_depth, p.grid, p.block) == (4, 1, 8, 256, 256) and p.lds_bytes <= 80 * 1024
+    lib = _lib.get()
+    q = _lib.Plan()
+    for (M, bits, g, N, K, tid) in ((1, 4, 64, 4096, 4416, 16), (2, 4, 128, 11008, 4096, 0), (4, 2, 64, 4096, 4096, 4),
+                                    (1, 3, 64, 8192, 8192, 4), (2, 3, 128, 4096, 4096, 4), (1, 4, 256, 3584, 8192, 16)):
+        assert lib.flute_qgemm_plan_ex(0, bits, g, M, N, K, tid, 256, 64 << 20, _lib.Overrides(family=0, one_shot=1), q) == 0
+        J = 16 if bits == 3 else 16 // bits
+        pieces = -(-K // 512)
+        assert q.one_shot >= 1 and q.splitk == 1 and q.waves % q.kw == 0 and q.block == q.waves * 64
+        assert -(-pieces // q.kw) <= q.ring_depth and q.grid == -(-(N // J) // (q.waves // q.kw))
+        assert q.lds_bytes <= 160 * 1024
+        if q.one_shot == 2:                                   # pipelined loop: every wave holds ring_depth pieces
+            assert bits == 4 and M == 1 and pieces == q.kw * q.ring_depth and (N // J) % (q.waves // q.kw) == 0
+    # one_shot = 0 / an explicit ring depth / group size 32: the persistent ring kernel
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=0), q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(ring_depth=4), q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 32, 1, 4096, 4096, 16, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
+    # template knobs: QuantMapMode digit 3 -> ring kernel, 1 / 2 -> one-shot with 4 / 8 pieces per wave
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 19, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 17, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 4
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 18, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 8
     # decode kernel: persistent grid never exceeds the unit groups
     rc, p = plan(1, 28672, 8192)
     assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4

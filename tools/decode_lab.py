@@ -44,7 +44,11 @@ def check():
     ]
     shapes = [dict(), dict(waves=16, kw=4), dict(waves=8, kw=2), dict(waves=14, kw=1), dict(waves=5, kw=1),
               dict(waves=16, kw=16), dict(waves=12, kw=4, ring_depth=2), dict(waves=8, kw=8, ring_depth=2),
-              dict(waves=1, kw=1), dict(waves=4, kw=2, splitk=2)]
+              dict(waves=1, kw=1), dict(waves=4, kw=2, splitk=2),
+              # one-shot kernel (qgemm_oneshot.h); combinations a shape cannot take (K too long for kw x depth) are skipped
+              dict(one_shot=0), dict(one_shot=1), dict(one_shot=1, ring_depth=4), dict(one_shot=1, ring_depth=8), dict(one_shot=1, ring_depth=2),
+              dict(one_shot=1, waves=8), dict(one_shot=1, waves=16), dict(one_shot=1, waves=8, kw=8), dict(one_shot=1, waves=16, kw=4),
+              dict(one_shot=1, waves=12, kw=4), dict(one_shot=1, waves=6, kw=2, ring_depth=4), dict(one_shot=1, waves=5, kw=1)]
     for (bits, tile_p, g, dtype, K, N) in cases:
         torch.manual_seed(K + N + bits)
         W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
@@ -81,6 +85,8 @@ def check():
                             rec["plan"] = dev.get_plan(M, N, K, bits, g, tid, sms, dtype, ovr)
                     except Exception as ex:  # noqa: BLE001
                         rec.update(ok=False, error=str(ex)[:300])
+                        if shp.get("one_shot") == 1 and "Unsupported shape" in str(ex):
+                            rec.update(ok=True, skipped=True)        # this launch shape does not exist for this K
                     if not rec["ok"]:
                         nfail += 1
                         emit(rec)
@@ -105,7 +111,7 @@ def time_case(M, N, K, bits, g, dtype, shp, steps=300, tile_p=32, hadamard=0, ta
     rec = {"kind": "time", "tag": tag, "M": M, "N": N, "K": K, "bits": bits, "g": g, "dtype": str(dtype)[6:], "shape": shp}
     try:
         rec["plan"] = {k: v for k, v in dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, lay.ovr).items()
-                       if k in ("family", "waves", "kw", "splitk", "grid", "lds_bytes", "ring_depth", "visits", "k_chunks")}
+                       if k in ("family", "waves", "kw", "splitk", "grid", "lds_bytes", "ring_depth", "visits", "k_chunks", "one_shot")}
         best = 1e9
         for _ in range(2):
             ms, _w = bench.time_graph(lay, steps, 10, torch.cuda.synchronize)
@@ -121,11 +127,20 @@ def time_case(M, N, K, bits, g, dtype, shp, steps=300, tile_p=32, hadamard=0, ta
 
 def timing(small_only=False):
     # headline: 4096 x 4096 W4G64 fp16 M=1
-    for shp in (dict(family=4), dict(), dict(waves=16, kw=4), dict(waves=16, kw=4, ring_depth=2), dict(waves=8, kw=2),
-                dict(waves=8, kw=4), dict(waves=16, kw=8, ring_depth=2), dict(waves=12, kw=4), dict(waves=16, kw=2),
-                dict(waves=8, kw=1), dict(waves=4, kw=1)):
+    one = [dict(one_shot=1, waves=w, ring_depth=d) for d in (8, 4) for w in (4, 8, 16)]
+    for shp in [dict(), dict(one_shot=0), dict(one_shot=0, waves=16, kw=4)] + one:
         time_case(1, 4096, 4096, 4, 64, f16, shp, steps=1000, tag="headline")
     if small_only:
+        for (tag, M, N, K, bits, dt, had) in (("11008", 1, 11008, 4096, 4, f16, 0), ("14336", 1, 14336, 4096, 4, f16, 0),
+                                              ("TP8 shard", 1, 3584, 8192, 4, f16, 0), ("higgs had512", 1, 4096, 3584, 4, f16, 512),
+                                              ("8192 W3", 1, 8192, 8192, 3, bf16, 0), ("big W4", 1, 28672, 8192, 4, f16, 0),
+                                              ("big W3", 1, 28672, 8192, 3, bf16, 0), ("down proj 70B", 1, 8192, 28672, 4, f16, 0),
+                                              ("M=2 4096", 2, 4096, 4096, 4, f16, 0), ("W2", 1, 4096, 4096, 2, f16, 0),
+                                              ("bf16 4096", 1, 4096, 4096, 4, bf16, 0), ("8192 g128", 1, 8192, 8192, 4, f16, 0)):
+            g = 128 if "g128" in tag else 64
+            ds = (4, 2) if bits == 3 else (8, 4)
+            for shp in [dict(one_shot=0)] + [dict(one_shot=1, waves=w, ring_depth=d) for d in ds for w in (4, 8, 16)]:
+                time_case(M, N, K, bits, g, dt, shp, steps=300, hadamard=had, tag=tag)
         return
     for shp in (dict(family=4), dict(), dict(waves=16, kw=1), dict(waves=11, kw=1, ring_depth=2), dict(waves=16, kw=4),
                 dict(waves=12, kw=1), dict(waves=8, kw=1)):
