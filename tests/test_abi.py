@@ -117,7 +117,7 @@ def test_plan_families_and_invariants():
     assert (p.waves, p.kw, p.ring_depth, p.grid, p.block) == (4, 1, 8, 256, 256) and p.lds_bytes <= 80 * 1024
     lib = _lib.get()
     q = _lib.Plan()
-    for (M, bits, g, N, K, tid) in ((1, 4, 64, 4096, 4416, 16), (2, 4, 128, 11008, 4096, 0), (4, 2, 64, 4096, 4096, 4),
+    for (M, bits, g, N, K, tid) in ((1, 4, 64, 4096, 4480, 16), (2, 4, 128, 11008, 4096, 0), (4, 2, 64, 4096, 4096, 4),
                                     (1, 3, 64, 8192, 8192, 4), (2, 3, 128, 4096, 4096, 4), (1, 4, 256, 3584, 8192, 16)):
         assert lib.flute_qgemm_plan_ex(0, bits, g, M, N, K, tid, 256, 64 << 20, _lib.Overrides(family=0, one_shot=1), q) == 0
         J = 16 if bits == 3 else 16 // bits
@@ -127,7 +127,9 @@ def test_plan_families_and_invariants():
         assert q.lds_bytes <= 160 * 1024
         if q.one_shot == 2:                                   # pipelined loop: every wave holds ring_depth pieces
             assert bits == 4 and M == 1 and pieces == q.kw * q.ring_depth and (N // J) % (q.waves // q.kw) == 0
-    # one_shot = 0 / an explicit ring depth / group size 32: the persistent ring kernel
+    # one_shot = 0 / an explicit ring depth / group size 32 / an odd number of groups (the one-shot kernel reads scale
+    # rows as aligned dwords): the persistent ring kernel
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4416, 16, 256, 64 << 20, _lib.Overrides(one_shot=1), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=0), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(ring_depth=4), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 32, 1, 4096, 4096, 16, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
