@@ -121,12 +121,15 @@ def flush_l3(device):
     """Untimed: push everything out of the 256 MiB Infinity Cache (and the L2s) by READING a 512 MiB scratch
     buffer (read-only: no dirty lines whose write-back would compete with the timed reads), so that the timed
     replay streams its weights from HBM whatever --steps is (20 steps of the headline touch 178 MB: without this
-    the warm replays would leave them cache-resident)."""
+    the warm replays would leave them cache-resident).  Enqueued on the replay stream right in front of the start
+    event, no host synchronisation in between: an idle gap would let the chip clock down, and a 20-step replay
+    (90 us) is shorter than the ramp back up."""
     buf = _FLUSH.get(device)
     if buf is None:
         buf = _FLUSH[device] = torch.zeros(2 * L3_BYTES // 4, dtype=torch.int32, device=device)
+        _FLUSH[(device, "sink")] = torch.zeros(1, dtype=torch.int64, device=device)
         torch.cuda.synchronize()
-    return int(buf.sum().item())                      # .item(): the flush has finished before the timed region starts
+    _FLUSH[(device, "sink")].add_(buf.sum())
 
 
 def time_graph(layer, steps, warmup, sync, cold=True):
@@ -143,11 +146,11 @@ def time_graph(layer, steps, warmup, sync, cold=True):
     for _ in range(3):                  # untimed: the first replay pays the upload, the next ones settle the clocks
         graph.replay()
     torch.cuda.synchronize()
-    if cold:
-        flush_l3(torch.device("cuda", torch.cuda.current_device()))
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync()
     t0 = time.perf_counter()
+    if cold:
+        flush_l3(torch.device("cuda", torch.cuda.current_device()))     # stream-ordered, in front of the start event
     start.record()
     graph.replay()
     end.record()

@@ -22,7 +22,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flute_amd", "csrc")
-UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip", "inst_block_b4.hip", "inst_block_b2.hip", "inst_block_b3.hip"]
+UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip", "inst_block_b4.hip", "inst_block_b2.hip", "inst_block_b3.hip", "inst_mid.hip",
+         "inst_oneshot_b4_f16.hip", "inst_oneshot_b4_bf16.hip", "inst_oneshot_b2_f16.hip", "inst_oneshot_b2_bf16.hip", "inst_oneshot_b3.hip"]
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*)\s+(\S+),")
@@ -174,7 +175,8 @@ def main(argv):
         for u in UNITS:
             out = os.path.join(tmp, u[:-4] + ".s")
             procs.append((out, subprocess.Popen(
-                ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only", "-o", out, u],
+                ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only"]
+                + (["-mllvm", "-amdgpu-kernarg-preload-count=14"] if u.startswith("inst_oneshot") else []) + ["-o", out, u],
                 cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
         files = []
         for out, pr in procs:
