@@ -22,7 +22,6 @@
 #include "mfma.h"
 #include "qgemm_tile.h"
 #include "qgemm_block.h"
-#include "qgemm_mid.h"
 
 using namespace flute_amd;
 
@@ -36,7 +35,6 @@ Ovr ovr_of(const flute_overrides* o) {
 
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
-constexpr int kFamilyMid = 5;                   // 64 / 128 x 64 tiles for mid-size batches (qgemm_mid.h)
 constexpr int kFamilyLegacyDecode = 4;          // round-1 decode kernel, reachable by override only (A/B runs)
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -423,41 +421,6 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         }
         if (blk_cfg >= 0) family = kFamilyBlock;
     }
-    // Mid-M kernel (qgemm_mid.h): 64 x 64 or 128 x 64 output tiles, 4- / 2-bit layers, scale rows in whole 16-B
-    // granules.  Taken by override (family 5, m_tiles 4 / 8), by the template (SMs_Multiple 2 / 4: 64- / 128-row
-    // tiles) or automatically for 33 <= M when neither block kernel fills the chip: cost model fitted to
-    // tools/block_lab.py `mid` (us per tile at K = 4096: 64-row 9, 128-row 14; two resident tiles per CU share it).
-    int mid_rt = 0;
-    {
-        const int mid_units = (bits == 4) ? 16 : 8;
-        // (lg >= 6: a scale block must outlive the ring's prefetch distance - 8 steps of 64 k)
-        const bool mid_ok = bits != 3 && lg >= 6 && (K >> lg) % 8 == 0 && units % mid_units == 0 && K % 64 == 0 && M >= 17 &&
-                            (size_t)(M + 128) * K * 2 < (size_t)0xfffffff0u;
-        if (mid_ok && ov.family == kFamilyMid) mid_rt = (ov.m_tiles == 8) ? 8 : 4;
-        else if (mid_ok && ov.family < 0 && family == 2 && M >= 33) {
-            if (t.sms_multiple == 2) mid_rt = 4;
-            else if (t.sms_multiple == 4) mid_rt = 8;
-            else {
-                auto mid_us = [&](int rt) {
-                    const long tiles = (long)ceil_div(M, rt * 16) * (units / mid_units);
-                    const int occ = (mid_lds_bytes(bits, rt) * 2 <= kMaxLds) ? 2 : 1;
-                    const long per_cu = ceil_div((int)tiles, num_sms);
-                    const double alone = (rt == 4 ? 9.0 : 14.0) * (double)K / 4096.0;
-                    const double rounds = (occ == 2) ? (per_cu / 2) * 1.6 + (per_cu % 2) : (double)per_cu;
-                    return rounds * alone + 2.0;
-                };
-                int dbl = 0;
-                for (int m = M; m >= 512; m >>= 1) ++dbl;
-                const bool bf = dtype == FLUTE_BF16;
-                const double base_tf = (M >= 256) ? (bf ? 400.0 : 520.0) : (bf ? 300.0 : 400.0) * (double)M / 256.0 + 60.0;
-                const double wave_tf = bf ? std::min(560.0, base_tf + 55.0 * dbl) : std::min(730.0, base_tf + 55.0 * dbl);
-                const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
-                const double t4 = mid_us(4), t8 = mid_us(8);
-                if (std::min(t4, t8) < wave_us) mid_rt = (t8 < t4) ? 8 : 4;
-            }
-        }
-        if (mid_rt) family = kFamilyMid;
-    }
     p->family = family;
 
     int rc = FLUTE_OK;
@@ -484,25 +447,6 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
     } else if (family == kFamilyLegacyDecode) {
         rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
-    } else if (family == kFamilyMid) {
-        const int mid_units = (bits == 4) ? 16 : 8;
-        const int tiles_m = ceil_div(M, mid_rt * 16), tiles_n = units / mid_units;
-        const int align_k = std::max(64, 8 << lg);
-        int splitk = (ov.splitk > 0) ? ov.splitk : 1;
-        int kps = round_up(ceil_div(K, splitk), align_k);
-        splitk = ceil_div(K, kps);
-        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
-            splitk >>= 1;
-            kps = round_up(ceil_div(K, splitk), align_k);
-            splitk = ceil_div(K, kps);
-        }
-        if (splitk == 1) kps = K;
-        p->m_block = 0; p->m_tiles = mid_rt; p->slabs_per_wave = 1; p->waves = 8; p->kw = 2;
-        p->splitk = splitk; p->k_per_split = kps;
-        p->grid = (unsigned)((long)tiles_m * tiles_n * splitk);
-        p->block = 512;
-        p->lds_bytes = (size_t)mid_lds_bytes(bits, mid_rt);
-        p->lut_copies = 32;
     } else if (family == kFamilyBlock) {
         const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
@@ -856,29 +800,6 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         }
         if (p.splitk > 1)
             return splitk_reduce_dispatch(dtype, sa.partial, D, (size_t)M * N, p.splitk, st);
-        return FLUTE_OK;
-    }
-
-    if (p.family == kFamilyMid) {
-        BlockArgs b;
-        memset(&b, 0, sizeof(b));
-        b.A = A; b.Q = reinterpret_cast<const uint32_t*>(Q); b.D = D; b.S = S;
-        b.QM2 = reinterpret_cast<const uint32_t*>(QM2);
-        b.partial = reinterpret_cast<float*>(workspace);
-        b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
-        b.tiles_m = ceil_div(M, p.m_tiles * 16); b.tiles_n = N / 64;
-        b.splitk = p.splitk; b.k_per_split = p.k_per_split;
-        b.order = (b.tiles_n % 8 == 0) ? 1 : 0;       // an XCD (block id % 8) runs the row blocks of one column range back to back
-        BlockKernel fn = (num_bits == 2) ? mid_kernel_b2(dtype, t.tile_p, p.m_tiles) : mid_kernel_b4(dtype, t.tile_p, p.m_tiles);
-        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
-        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
-        void* kargs[] = {&b};
-        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
-            hipSuccess) {
-            (void)hipGetLastError();
-            return FLUTE_ERR_LAUNCH;
-        }
-        if (p.splitk > 1) return splitk_reduce_dispatch(dtype, b.partial, D, (size_t)M * N, p.splitk, st);
         return FLUTE_OK;
     }
 

@@ -31,9 +31,6 @@ typedef void (*BlockKernel)(const BlockArgs);
 BlockKernel block_kernel_b4(int dtype, int tile_p, int cfg);
 BlockKernel block_kernel_b2(int dtype, int tile_p, int cfg);
 BlockKernel block_kernel_b3(int dtype, int tile_p, int cfg);
-// mid-M kernel (qgemm_mid.h): rt = row tiles of the 64-column tile (4 / 8)
-BlockKernel mid_kernel_b4(int dtype, int tile_p, int rt);
-BlockKernel mid_kernel_b2(int dtype, int tile_p, int rt);
 // MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw);   // sw: slabs per wave (1, 2)
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);

@@ -153,122 +153,7 @@ def timing_b2(bits=2):
                 torch.cuda.empty_cache()
 
 
-def check_mid():
-    """qgemm_mid.h (family 5): 64- and 128-row tiles, 4- and 2-bit layers, against the fp32 reference; one-hot rows exact."""
-    nfail = 0
-    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
-                                           (4, 32, 32, f16, 1024, 256), (4, 64, 256, bf16, 4096, 256), (4, 32, 64, f16, 4096, 11008),
-                                           (4, 32, 64, bf16, 1536, 128), (4, 32, 64, f16, 512, 64 * 5),
-                                           (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (2, 32, 32, bf16, 1024, 256),
-                                           (2, 64, 256, f16, 3072, 512)]:
-        if N % (16 // bits * tile_p):
-            continue
-        torch.manual_seed(K + N)
-        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
-        S = torch.randn(N, K // g, device=d).to(dtype)
-        table = torch.randn(2 ** bits, device=d).to(dtype)
-        table2 = utils.make_qmap2_from_qmap(table)
-        tid = tid_of(bits, tile_p)
-        Q = utils.pack(W, bits, [tid], num_sms)
-        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
-        tol = 1e-3 if dtype == f16 else 8e-3
-        for M in (17, 64, 100, 256, 300, 1024):
-            X = (torch.randn(M, K, device=d) / 100).to(dtype)
-            ref = X.float() @ What.float()
-            ks = torch.randint(0, K, (M,), device=d)
-            E = torch.zeros(M, K, device=d, dtype=dtype)
-            E[torch.arange(M, device=d), ks] = 1
-            for shp in (dict(family=5, m_tiles=4), dict(family=5, m_tiles=8), dict(family=5, m_tiles=4, splitk=2), dict(family=5, m_tiles=8, splitk=4)):
-                rec = {"kind": "check_mid", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "shape": shp}
-                try:
-                    ovr = dev.Overrides(**shp)
-                    pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
-                    if pl["family"] != 5:
-                        rec.update(ok=True, skipped=True, family=pl["family"])
-                        emit(rec)
-                        continue
-                    out = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
-                    out1 = dev.qgemm_planned(E, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
-                    torch.cuda.synchronize()
-                    err = ((out.float() - ref).norm() / ref.norm()).item()
-                    exact = bool(torch.equal(out1, What[ks]))
-                    rec.update(err=err, onehot_exact=exact, ok=bool(err < tol and exact))
-                    if not rec["ok"]:
-                        bad = ((out.float() - ref).abs() > 0.05 * ref.abs().max()) | out.float().isnan()
-                        rec["nbad"] = int(bad.sum().item())
-                        rec["bad_rows"] = bad.any(1).nonzero().flatten()[:10].tolist()
-                        rec["bad_cols"] = bad.any(0).nonzero().flatten()[:16].tolist()
-                        rec["onehot_mismatch"] = int((out1 != What[ks]).sum().item())
-                except Exception as ex:  # noqa: BLE001
-                    rec.update(ok=False, error=str(ex)[:300])
-                if not rec["ok"]:
-                    nfail += 1
-                    emit(rec)
-                else:
-                    rows.append(rec)
-        del W, S, Q, What
-        torch.cuda.empty_cache()
-    emit({"kind": "check_mid_summary", "failed": nfail, "total": len([r for r in rows if r.get("kind") == "check_mid"])})
-    return nfail
-
-
-def timing_mid():
-    for (M, N, K) in ((256, 4096, 4096), (256, 11008, 4096), (512, 4096, 4096), (1024, 4096, 4096), (128, 4096, 4096), (64, 4096, 4096),
-                      (512, 11008, 4096), (1024, 11008, 4096), (256, 8192, 8192), (256, 28672, 8192), (128, 11008, 4096), (64, 8192, 8192)):
-        for dtype in (f16, bf16):
-            if dtype == bf16 and (N, K) != (4096, 4096):
-                continue
-            for shp in (dict(family=2), dict(family=5, m_tiles=4), dict(family=5, m_tiles=8), dict(family=3, m_tiles=4, slabs_per_wave=3), dict()):
-                lay = bench.Layer(M, N, K, 4, 64, dtype, d, bench.copies_for(N, K, 4))
-                lay.template_id = 16
-                if shp.get("family") == 2:
-                    os.environ["FLUTE_AMD_RETUNE"] = "1"
-                    try:
-                        lay.ovr = dev.Overrides(family=2)
-                        from flute_amd import tune
-                        cands = [t for t in tune.candidate_templates(M, N, K, 4, 64, num_sms, dtype) if flute_amd.TEMPLATE_CONFIGS[(4, t)]["TileP"] == 32]
-                        best = (1e9, 16)
-                        for t in cands:
-                            lay.template_id = t
-                            if dev.get_plan(M, N, K, 4, 64, t, num_sms, dtype, lay.ovr)["family"] != 2:
-                                continue
-                            ms = bench.time_graph(lay, 50, 3, torch.cuda.synchronize)[0]
-                            best = min(best, (ms, t))
-                        lay.template_id = best[1]
-                    finally:
-                        os.environ.pop("FLUTE_AMD_RETUNE", None)
-                else:
-                    lay.ovr = dev.Overrides(**shp)
-                rec = {"kind": "time_mid", "M": M, "N": N, "K": K, "dtype": str(dtype)[6:], "shape": shp, "template_id": lay.template_id}
-                try:
-                    pl = dev.get_plan(M, N, K, 4, 64, lay.template_id, num_sms, dtype, lay.ovr)
-                    rec["plan"] = {k: pl[k] for k in ("family", "m_block", "m_tiles", "waves", "kw", "splitk", "grid")}
-                    steps = 200
-                    ms = min(bench.time_graph(lay, steps, 5, torch.cuda.synchronize)[0] for _ in range(2))
-                    us = ms / steps * 1e3
-                    rec.update(us=round(us, 2), TFLOPs=round(lay.flops() / us / 1e6, 1), frac=round(lay.flops() / us / 1e6 / 2500, 3))
-                except Exception as ex:  # noqa: BLE001
-                    rec["error"] = str(ex)[:200]
-                emit(rec)
-                del lay
-                torch.cuda.empty_cache()
-        Wd = [torch.randn(K, N, device=d, dtype=f16) for _ in range(max(2, (300 << 20) // (K * N * 2) + 1))]
-        Xd = torch.randn(M, K, device=d, dtype=f16)
-
-        class Dense:
-            def step(self, i):
-                return torch.mm(Xd, Wd[i % len(Wd)])
-        ms, _ = bench.time_graph(Dense(), 100, 5, torch.cuda.synchronize)
-        emit({"kind": "time_mid", "M": M, "N": N, "K": K, "shape": "torch.mm fp16", "us": round(ms * 10, 2), "TFLOPs": round(2 * M * N * K / (ms * 10) / 1e6, 1)})
-        del Wd, Xd
-        torch.cuda.empty_cache()
-
-
 rc = 0
-if "check_mid" in what:
-    rc = check_mid()
-if "time_mid" in what:
-    timing_mid()
 if "time_b2" in what:
     timing_b2()
 if "time_b3" in what:
