@@ -16,7 +16,6 @@
 
 #include "../../include/flute_amd.h"
 #include "kernels.h"
-#include "qgemm_decode.h"
 #include "qgemm_stream.h"
 #include "qgemm_oneshot.h"
 #include "mfma.h"
@@ -35,13 +34,12 @@ Ovr ovr_of(const flute_overrides* o) {
 
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
-constexpr int kFamilyLegacyDecode = 4;          // round-1 decode kernel, reachable by override only (A/B runs)
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
-// rows of a block-kernel configuration (flute_plan::m_block of family 3): 0..7 = 256 / 128 rows (even / odd),
+// rows of a block-kernel configuration (flute_plan::m_block of family 3): 4 / 5 = 256 / 128 rows,
 // 8 + RT = the skinny 3-bit blocks of RT row tiles
 int block_rows(int cfg) { return cfg >= 8 ? (cfg - 8) * 16 : ((cfg & 1) ? 128 : 256); }
 
@@ -295,52 +293,6 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     return FLUTE_OK;
 }
 
-// round-1 decode kernel (qgemm_decode.h), kept for A/B measurements: override family = 4
-int plan_legacy_decode(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
-                       const Ovr& ov, size_t workspace_bytes, flute_plan* p) {
-    const int J = (bits == 3) ? 16 : 16 / bits;
-    const int units = N / J, lines = K / 64;
-    const int dec_max = 4;
-    int mb = 1; while (mb < M) mb <<= 1;
-    if (ov.m_block > 0 && ov.m_block >= M && ov.m_block <= dec_max) mb = ov.m_block;
-    int waves = t.threads / 64;
-    if (ov.waves > 0) waves = floor_pow2(ov.waves);
-    if (waves > dec_max_threads(bits, mb) / 64) waves = dec_max_threads(bits, mb) / 64;
-    if (waves < 1) waves = 1;
-    const long target_waves = (long)num_sms * t.sms_multiple * waves;
-    int f = 1;
-    while ((long)units * f < target_waves && lines / (f * 2) >= 8) f *= 2;
-    int kw = f < waves ? f : waves;
-    int splitk = f / kw;
-    if (ov.kw > 0) kw = floor_pow2(ov.kw);
-    if (ov.splitk > 0) splitk = ov.splitk;
-    if (kw > waves) kw = waves;
-    while (waves % kw) kw >>= 1;
-    while ((units % (waves / kw)) && kw < waves) kw <<= 1;
-    int kps = round_up(ceil_div(K, splitk), 512);
-    splitk = ceil_div(K, kps);
-    while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
-        splitk >>= 1;
-        kps = round_up(ceil_div(K, splitk), 512);
-        splitk = ceil_div(K, kps);
-    }
-    if (splitk == 1) kps = K;
-    const DecodeGeom geo = decode_geom(bits, mb, lg, waves, kw, kps, kMaxLds);
-    const int ngroups = units / (waves / kw);
-    int occ = (int)(kMaxLds / geo.total);
-    if (occ > 2048 / (waves * 64)) occ = 2048 / (waves * 64);
-    if (occ < 1) occ = 1;
-    long nwg = (long)num_sms * occ;
-    if (nwg > ngroups) nwg = ngroups;
-    p->family = kFamilyLegacyDecode;
-    p->m_block = mb; p->waves = waves; p->kw = kw; p->splitk = splitk; p->k_per_split = kps;
-    p->grid = (unsigned)(nwg * splitk);
-    p->block = (unsigned)(waves * 64);
-    p->lds_bytes = geo.total;
-    p->lut_copies = (bits == 4) ? 64 : 32;
-    return FLUTE_OK;
-}
-
 int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
               StreamArgs* sa, OneArgs* oa) {
@@ -368,11 +320,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const int dec_max = 4;
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
     int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
-    if (ov.family == kFamilyLegacyDecode && M <= dec_max) family = kFamilyLegacyDecode;
-    else if (ov.family >= 1) family = 2;          // any M may be forced through the MFMA kernel
+    if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
-    // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks; qgemm_block.h, the 2 x 4
-    // wave split of 4-bit layers, stays reachable by override); scale rows in whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
+    // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks); scale rows in
+    // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
     //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
@@ -385,11 +336,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         (family == 2 || ov.family == kFamilyBlock) && (ov.family < 0 || ov.family == kFamilyBlock)) {
         const long tiles256 = (long)ceil_div(M, 256) * (units / blk_units), tiles128 = (long)ceil_div(M, 128) * (units / blk_units);
         if (ov.family == kFamilyBlock) {
-            blk_cfg = (ov.m_tiles == 4) ? 1 : 0;
-            // slabs_per_wave: 1 lockstep / 2 software-pipelined schedule of the 2 x 4 split; 3 or automatic: 1 x 8 split
-            if (ov.slabs == 2) blk_cfg |= 2;
-            else if (ov.slabs != 1) blk_cfg += 4;
-            if (bits == 2) blk_cfg = 4 + (blk_cfg & 1);      // the 2 x 4 split (either schedule) exists for 4-bit layers only
+            blk_cfg = (ov.m_tiles == 4) ? 5 : 4;             // 128- / 256-row blocks of qgemm_block2.h
             if (bits == 3) blk_cfg = 5;                      // 3-bit layers: 128-row blocks of qgemm_block3.h ...
             if (bits == 3 && (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4))
                 blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
@@ -445,8 +392,6 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             }
         }
         if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
-    } else if (family == kFamilyLegacyDecode) {
-        rc = plan_legacy_decode(bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p);
     } else if (family == kFamilyBlock) {
         const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
@@ -601,11 +546,6 @@ StreamKernel pick_stream_kernel(int bits, int dtype, int tile_p, int mb, int dep
 }
 
 QGemmKernel pick_kernel(int family, int bits, int dtype, int tile_p, int mblk, int mtiles, int sw) {
-    if (family == kFamilyLegacyDecode) {
-        if (bits == 4) return decode_kernel_b4(dtype, tile_p, mblk, 0);
-        if (bits == 3) return decode_kernel_b3(dtype, tile_p, mblk, 0);
-        return decode_kernel_b2(dtype, tile_p, mblk, 0);
-    }
     if (bits == 4) return tile_kernel_b4(dtype, tile_p, mblk, mtiles, sw);
     if (bits == 3) return tile_kernel_b3(dtype, tile_p, mblk, mtiles);
     return tile_kernel_b2(dtype, tile_p, mblk, mtiles);
@@ -634,7 +574,7 @@ int ensure_lds(const void* fn, size_t bytes) {
 }
 
 bool hadamard_fusable(const flute_plan& p, int hadamard_size, int K) {
-    return (p.family == 0 || p.family == kFamilyLegacyDecode) && hadamard_size >= 2 && hadamard_size <= 512 &&
+    return p.family == 0 && hadamard_size >= 2 && hadamard_size <= 512 &&
            (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0;
 }
 
@@ -844,13 +784,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     a.had_log = had_log;
     a.had_scale = had_scale;
     for (int i = 0; i < 10; ++i) a.geo[i] = 0;
-    if (p.family == kFamilyLegacyDecode) {
-        const DecodeGeom g = decode_geom(num_bits, p.m_block, a.lg, p.waves, p.kw, p.k_per_split, kMaxLds);
-        a.geo[0] = g.kc; a.geo[1] = g.nbuf; a.geo[2] = g.gcap; a.geo[3] = ilog2(g.upw);
-        a.geo[4] = (int)g.x_off; a.geo[5] = (int)g.s_off; a.geo[6] = (int)g.red_off; a.geo[7] = ilog2(g.kc);
-        const int ngroups = a.units / g.upw, nwg = (int)p.grid / p.splitk;
-        a.geo[8] = ngroups / nwg; a.geo[9] = ngroups % nwg;
-    } else {
+    {
         const TileGeom g = tile_geom(num_bits, p.m_block, p.m_tiles, p.slabs_per_wave, p.waves, kMaxLds);
         a.geo[0] = g.depth; a.geo[1] = g.scale_bytes; a.geo[2] = g.slot_bytes; a.geo[3] = g.wave_bytes;
         a.geo[4] = ceil_div(M, p.m_tiles * 16);

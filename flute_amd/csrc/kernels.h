@@ -6,11 +6,6 @@ namespace flute_amd {
 
 typedef void (*QGemmKernel)(const QGemmArgs);
 
-// dtype: 0 fp16, 1 bf16; tile_p: 32 / 64; mb in {1,2,4} (b=3: {1,2}); mt in {1,2,4};
-// pre: 1 = per-pair scale rounding (fp16 only)
-QGemmKernel decode_kernel_b4(int dtype, int tile_p, int mb, int pre);
-QGemmKernel decode_kernel_b3(int dtype, int tile_p, int mb, int pre);
-QGemmKernel decode_kernel_b2(int dtype, int tile_p, int mb, int pre);
 // streaming decode kernel (qgemm_stream.h): mb rows per pass (1/2/4; b=3: 1/2), depth = ring slots (2/4), one_shot = the no-refill variant (b=2/4: depth 4, b=3: depth 2)
 struct StreamArgs;
 typedef void (*StreamKernel)(const StreamArgs);
@@ -25,7 +20,7 @@ OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pip
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had);
-// block-tiled prefill kernel (qgemm_block.h): cfg 0 = 256 x 256 block, cfg 1 = 128 x 256
+// block-tiled prefill kernels (qgemm_block2.h / qgemm_block3.h): cfg 4 = 256 x 256 block, cfg 5 = 128 x 256, 8 + RT = skinny 3-bit blocks
 struct BlockArgs;
 typedef void (*BlockKernel)(const BlockArgs);
 BlockKernel block_kernel_b4(int dtype, int tile_p, int cfg);

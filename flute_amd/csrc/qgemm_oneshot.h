@@ -57,11 +57,6 @@ __device__ __forceinline__ uint32_t buf_load4_at(uint32_t voff, srd_t srd, uint3
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
     return v;
 }
-__device__ __forceinline__ ring16_t buf_load16_nt(uint32_t voff, srd_t srd, uint32_t soff) {
-    ring16_t v;
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
-    return v;
-}
 // hidden LDS reads of the pipelined piece loop (released by the counted lgkmcnt of the lookups behind them)
 __device__ __forceinline__ ring16_t lds_hidden128(uint32_t addr) {
     ring16_t v;

@@ -89,6 +89,12 @@ __device__ __forceinline__ ring16_t buf_load16(uint32_t voff, srd_t srd, uint32_
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
     return v;
 }
+// the same with the non-temporal cache policy: weights are streamed once (MI355X_MICROARCH.md, nt-weights)
+__device__ __forceinline__ ring16_t buf_load16_nt(uint32_t voff, srd_t srd, uint32_t soff) {
+    ring16_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    return v;
+}
 __device__ __forceinline__ uint32_t buf_load4(uint32_t voff, srd_t srd) {
     uint32_t v;
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(srd) : "memory");
@@ -357,7 +363,13 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
         // past the end of a ragged row into zeros
         const uint32_t vo = lane16 + ((lp < lnp) ? lsoff : 0x80000000u);
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) q[i][pl] = buf_load16(vo, lsrd[pl], 0);
+        for (int pl = 0; pl < NP; ++pl) {
+#ifdef FLUTE_RING_NO_NT
+            q[i][pl] = buf_load16(vo, lsrd[pl], 0);
+#else
+            q[i][pl] = buf_load16_nt(vo, lsrd[pl], 0);
+#endif
+        }
         lsoff += 1024u;
         ++lp;
     };

@@ -65,7 +65,7 @@ typedef struct flute_template_info {
 
 /* Launch plan chosen for a problem (host logic only, no GPU needed). */
 typedef struct flute_plan {
-    int family;          /* 0 = decode (streaming GEMV, M<=4; 3 bits: M<=2), 2 = MFMA kernel with
+    int family;          /* 0 = decode (GEMV kernels, M<=4; 3 bits: M<=2; see one_shot), 2 = MFMA kernel with
                             LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
                             (4-bit, enough 128/256 x 256 output blocks to fill the chip) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
@@ -89,11 +89,9 @@ typedef struct flute_plan {
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
- *   family          0 streaming decode kernel also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
+ *   family          0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
- *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block;
- *                   slabs_per_wave 1 / 2: the 2 x 4 wave split, lockstep / software-pipelined, 4-bit only),
- *                   4 round-1 decode kernel
+ *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split

@@ -178,9 +178,10 @@ def test_forced_splitk_and_kw_variants(env):
                     D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, ovr)
                     err = rel_err(D, ref)
                     assert err < FP16_TOL, (M, ovr, err)
-        if M <= 4:
-            D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=4))
-            assert rel_err(D, ref) < FP16_TOL, (M, "legacy decode")
+        if M <= 4:                                   # both decode kernels, forced
+            for one in (0, 1):
+                D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=0, one_shot=one))
+                assert rel_err(D, ref) < FP16_TOL, (M, "one_shot", one)
 
 
 def test_decode_plan_shapes(env):
@@ -321,13 +322,9 @@ def test_block_prefill_kernel(env):
             E = torch.zeros(M, K, dtype=dtype)
             E[torch.arange(M), ks] = 1
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
-            # slabs_per_wave 3 (what the planner takes): 1 x 8 wave split (qgemm_block2.h); 1 / 2: lockstep /
-            # software-pipelined schedule of the 2 x 4 split (qgemm_block.h)
-            for shp in (dict(family=3, m_tiles=8, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3),
-                        dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=3), dict(family=3, m_tiles=4, splitk=2, slabs_per_wave=3),
-                        dict(family=3, m_tiles=8, slabs_per_wave=1), dict(family=3, m_tiles=4, slabs_per_wave=1),
-                        dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=1), dict(family=3, m_tiles=8, slabs_per_wave=2),
-                        dict(family=3, m_tiles=4, slabs_per_wave=2), dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=2)):
+            # 256- / 128-row blocks of the 1 x 8 wave split (qgemm_block2.h), with and without a grid K split
+            for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4),
+                        dict(family=3, m_tiles=8, splitk=2), dict(family=3, m_tiles=4, splitk=2)):
                 ovr = dev.Overrides(**shp)
                 assert dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)["family"] == 3
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()

@@ -52,8 +52,7 @@ def check():
             E = torch.zeros(M, K, device=d, dtype=dtype)
             E[torch.arange(M, device=d), ks] = 1
             for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, splitk=2),
-                        dict(family=3, m_tiles=8, slabs_per_wave=2), dict(family=3, m_tiles=4, slabs_per_wave=2),
-                        dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=2), dict(family=3, m_tiles=8, slabs_per_wave=3),
+                        dict(family=3, m_tiles=8, slabs_per_wave=3),
                         dict(family=3, m_tiles=8, splitk=2, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3),
                         dict(family=3, m_tiles=4, splitk=2, slabs_per_wave=3)):
                 rec = {"kind": "check", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "shape": shp}
@@ -90,8 +89,7 @@ def timing():
                       (512, 11008, 4096), (256, 11008, 4096), (512, 4096, 4096), (2048, 11008, 4096), (1024, 8192, 8192), (512, 28672, 8192),
                       (256, 4096, 4096), (256, 28672, 8192), (256, 8192, 8192), (128, 11008, 4096), (128, 28672, 8192)):
         for dtype in (f16, bf16):
-            for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, slabs_per_wave=2),
-                        dict(family=3, m_tiles=4, slabs_per_wave=2), dict(family=3, m_tiles=8, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3), dict()):
+            for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict(family=3, m_tiles=8, slabs_per_wave=3), dict(family=3, m_tiles=4, slabs_per_wave=3), dict()):
                 lay = bench.Layer(M, N, K, 4, 64, dtype, d, bench.copies_for(N, K, 4))
                 lay.template_id = 16
                 if shp.get("family") == 2:

@@ -142,19 +142,19 @@ def timing(small_only=False):
             for shp in [dict(one_shot=0)] + [dict(one_shot=1, waves=w, ring_depth=d) for d in ds for w in (4, 8, 16)]:
                 time_case(M, N, K, bits, g, dt, shp, steps=300, hadamard=had, tag=tag)
         return
-    for shp in (dict(family=4), dict(), dict(waves=16, kw=1), dict(waves=11, kw=1, ring_depth=2), dict(waves=16, kw=4),
+    for shp in (dict(), dict(waves=16, kw=1), dict(waves=11, kw=1, ring_depth=2), dict(waves=16, kw=4),
                 dict(waves=12, kw=1), dict(waves=8, kw=1)):
         time_case(1, 11008, 4096, 4, 64, f16, shp, steps=500, tag="11008")
-    for shp in (dict(family=4), dict(), dict(waves=14, kw=1, ring_depth=2), dict(waves=16, kw=1), dict(waves=16, kw=4),
+    for shp in (dict(), dict(waves=14, kw=1, ring_depth=2), dict(waves=16, kw=1), dict(waves=16, kw=4),
                 dict(waves=7, kw=1), dict(waves=15, kw=1), dict(waves=10, kw=1)):
         time_case(1, 28672, 8192, 4, 64, f16, shp, steps=200, tag="big W4")
-    for shp in (dict(family=4), dict(), dict(waves=16, kw=2), dict(waves=8, kw=1), dict(waves=14, kw=2), dict(waves=16, kw=4)):
+    for shp in (dict(), dict(waves=16, kw=2), dict(waves=8, kw=1), dict(waves=14, kw=2), dict(waves=16, kw=4)):
         time_case(1, 28672, 8192, 3, 64, bf16, shp, steps=200, tag="big W3")
-    for shp in (dict(family=4), dict(), dict(waves=16, kw=8), dict(waves=8, kw=4), dict(waves=16, kw=4)):
+    for shp in (dict(), dict(waves=16, kw=8), dict(waves=8, kw=4), dict(waves=16, kw=4)):
         time_case(1, 8192, 8192, 3, 64, bf16, shp, steps=300, tag="8192 W3")
-    for shp in (dict(family=4), dict(), dict(waves=16, kw=4), dict(waves=14, kw=2)):
+    for shp in (dict(), dict(waves=16, kw=4), dict(waves=14, kw=2)):
         time_case(1, 3584, 8192, 4, 64, f16, shp, steps=500, tag="TP8 shard")
-    for shp in (dict(family=4), dict()):
+    for shp in (dict()):
         time_case(1, 4096, 3584, 4, 64, f16, shp, steps=500, hadamard=512, tag="higgs had512")
         time_case(1, 8192, 28672, 4, 64, f16, shp, steps=200, tag="down proj 70B")
         time_case(4, 4096, 4096, 4, 64, f16, shp, steps=500, tag="M=4")
@@ -162,6 +162,18 @@ def timing(small_only=False):
         time_case(1, 4096, 4096, 2, 64, f16, shp, steps=500, tag="W2")
         time_case(1, 8192, 8192, 4, 128, f16, shp, steps=300, tag="8192 g128")
         time_case(1, 4096, 4096, 4, 64, bf16, shp, steps=500, tag="bf16 4096")
+
+
+def timing_ring():
+    """The persistent ring kernel on the layers that keep it (one_shot = 0): A/B of library builds."""
+    for (tag, M, N, K, bits, dt) in (("big W4", 1, 28672, 8192, 4, f16), ("down proj 70B", 1, 8192, 28672, 4, f16), ("big W3", 1, 28672, 8192, 3, bf16),
+                                     ("8192 W3", 1, 8192, 8192, 3, bf16), ("8192 g64", 1, 8192, 8192, 4, f16), ("M=2 big", 2, 28672, 8192, 4, f16),
+                                     ("14336x8192", 1, 14336, 8192, 4, f16), ("W2 big", 1, 28672, 8192, 2, f16)):
+        shapes = [dict(one_shot=0), dict(one_shot=0, ring_depth=2), dict(one_shot=0, ring_depth=4)]
+        if bits != 3:
+            shapes += [dict(one_shot=0, waves=16, kw=2), dict(one_shot=0, waves=12, kw=1)]
+        for shp in shapes:
+            time_case(M, N, K, bits, 64, dt, shp, steps=200, tag=tag)
 
 
 t0 = time.time()
@@ -172,6 +184,8 @@ if "time" in what:
     timing()
 if "time_small" in what:
     timing(small_only=True)
+if "time_ring" in what:
+    timing_ring()
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump([r for r in rows if r.get("kind") != "check" or not r.get("ok")], open("gpurun_out/decode_lab.json", "w"), indent=1)
 print(f"decode_lab done in {time.time() - t0:.1f}s, failures: {rc}")
