@@ -1,9 +1,11 @@
 """vLLM glue (flute/integrations/vllm_utils.py:42-349, vllm.py:9-46) against the CURRENT operator signature.
 
 vLLM is not part of the build image, so the two vLLM-facing classes (`FluteConfig`, `FluteLinearMethod`) are
-only defined when `vllm` imports and have never run against it; the part that carries the logic -
-`repack_loaded_shard`, what `process_weights_after_loading` does to the tensors vLLM's loader produced - is a
-plain function and is tested on the GPU (tests/test_vllm_utils_gpu.py) by loading shards the way vLLM does.
+only defined when `vllm` imports.  They are executed on the GPU against a stub of the four vLLM names they use
+(tests/test_vllm_utils_gpu.py: create_weights -> a `params_dict[name]` load of a FluteLinear state dict ->
+process_weights_after_loading -> apply); the part that carries the logic - `repack_loaded_shard`, what
+`process_weights_after_loading` does to the tensors vLLM's loader produced - is a plain function and is tested
+by loading shards the way vLLM cuts them.
 
 Difference from the reference: it all-gathers every shard (int16 cast to int32 for NCCL), unpacks the full
 matrix with an identity-matrix qgemm, re-shards and repacks on the CPU (vllm_utils.py:228-326).  The packed format
@@ -142,9 +144,16 @@ if _HAVE_VLLM:                                         # pragma: no cover
             set_weight_attrs(scales, {**extra_weight_attrs, "input_dim": 1, "output_dim": 0})
             tables = Parameter(torch.arange(2 ** cfg.num_bits, dtype=params_dtype, device=dev), requires_grad=False)
             set_weight_attrs(tables, {**extra_weight_attrs, "input_dim": None, "output_dim": None, "ignore_warning": True})
+            # the pair table is part of every FLUTE checkpoint (`...tables2`, vllm_utils.py:196-218): vLLM's loader
+            # looks every checkpoint tensor up in params_dict, so it must exist as a parameter; the loaded value
+            # is replaced by make_qmap2_from_qmap(tables) after loading (loaders may have cast it, huggingface.py:221-232)
+            tables2 = Parameter(torch.zeros((2 ** cfg.num_bits, 2 ** cfg.num_bits, 1), dtype=torch.float32, device=dev),
+                                requires_grad=False)
+            set_weight_attrs(tables2, {**extra_weight_attrs, "input_dim": None, "output_dim": None, "ignore_warning": True})
             layer.register_parameter("weight", weight)
             layer.register_parameter("scales", scales)
             layer.register_parameter("tables", tables)
+            layer.register_parameter("tables2", tables2)
             layer.flute_output_partition_sizes = list(output_partition_sizes)
             layer.flute_template_id = None
             layer.needs_repacking = True
@@ -157,13 +166,13 @@ if _HAVE_VLLM:                                         # pragma: no cover
                                          cfg.num_bits, cfg.group_size)
             layer.weight = Parameter(Q, requires_grad=False)
             layer.flute_template_id = tid
-            layer.flute_tables2 = flute_amd.utils.make_qmap2_from_qmap(layer.tables.data)
+            layer.tables2 = Parameter(flute_amd.utils.make_qmap2_from_qmap(layer.tables.data), requires_grad=False)
             layer.flute_workspace = flute_amd.utils.get_workspace_streamk(Q.device)
             layer.flute_num_sms = flute_amd.utils.get_device_num_sms(Q.device)
             layer.needs_repacking = False
 
         def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-            out = flute_amd.qgemm(x, layer.weight, layer.scales, layer.tables, layer.flute_tables2, layer.flute_workspace,
+            out = flute_amd.qgemm(x, layer.weight, layer.scales, layer.tables, layer.tables2, layer.flute_workspace,
                                   self.quant_config.num_bits, self.quant_config.group_size, layer.flute_template_id,
                                   layer.flute_num_sms)
             return out if bias is None else out.add_(bias)

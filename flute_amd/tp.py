@@ -16,7 +16,7 @@ Collectives go through torch.distributed (backend "nccl" == RCCL over xGMI on
 ROCm; "gloo" in the CPU tests).  The decode-size message (M*N*2 B = 16 KB at
 M=1, N=8192) is latency-bound: one all-reduce per row-parallel layer, never more.
 """
-from typing import Callable, Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist
@@ -56,9 +56,16 @@ def shard_rows(Q: torch.Tensor, S: torch.Tensor, group_size: int, world: int, ra
     return Q[:, k0:k1].contiguous(), S[:, k0 // group_size: k1 // group_size].contiguous()
 
 
+def local_qgemm(x, Q, S, table, table2, num_bits, group_size, template_id):
+    """The per-rank product: flute.qgemm on this rank's shard (the HIP kernel; there is no CPU path)."""
+    import flute_amd
+    from flute_amd import utils
+    return flute_amd.qgemm(x, Q, S, table, table2, utils.get_workspace_streamk(x.device), num_bits,
+                           group_size, template_id, utils.get_device_num_sms(x.device))
+
+
 class _ParallelQLinear(torch.nn.Module):
-    def __init__(self, Q, S, table, table2, num_bits, group_size, template_id,
-                 qgemm_fn: Optional[Callable] = None, group=None):
+    def __init__(self, Q, S, table, table2, num_bits, group_size, template_id, group=None):
         super().__init__()
         self.register_buffer("weight", Q)
         self.register_buffer("scales", S)
@@ -66,18 +73,10 @@ class _ParallelQLinear(torch.nn.Module):
         self.register_buffer("tables2", table2)
         self.num_bits, self.group_size, self.template_id = num_bits, group_size, template_id
         self.group = group
-        self._qgemm_fn = qgemm_fn
 
     def _local(self, x):
-        if self._qgemm_fn is not None:       # injected by the gloo/CPU tests (oracle)
-            return self._qgemm_fn(x, self.weight, self.scales, self.tables, self.tables2,
-                                  self.num_bits, self.group_size, self.template_id)
-        import flute_amd
-        from flute_amd import utils
-        return flute_amd.qgemm(x, self.weight, self.scales, self.tables, self.tables2,
-                               utils.get_workspace_streamk(x.device), self.num_bits,
-                               self.group_size, self.template_id,
-                               utils.get_device_num_sms(x.device))
+        return local_qgemm(x, self.weight, self.scales, self.tables, self.tables2,
+                           self.num_bits, self.group_size, self.template_id)
 
 
 class ColumnParallelQLinear(_ParallelQLinear):
@@ -86,10 +85,10 @@ class ColumnParallelQLinear(_ParallelQLinear):
 
     @classmethod
     def from_full(cls, Q, S, table, table2, num_bits, group_size, template_id, tile_p,
-                  gather_output=False, qgemm_fn=None, group=None):
+                  gather_output=False, group=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         q, s = shard_columns(Q, S, num_bits, tile_p, world, rank)
-        m = cls(q, s, table, table2, num_bits, group_size, template_id, qgemm_fn, group)
+        m = cls(q, s, table, table2, num_bits, group_size, template_id, group)
         m.gather_output = gather_output
         return m
 
@@ -108,11 +107,10 @@ class RowParallelQLinear(_ParallelQLinear):
     of a column-parallel layer); ONE all-reduce(sum) of M*N*2 bytes."""
 
     @classmethod
-    def from_full(cls, Q, S, table, table2, num_bits, group_size, template_id,
-                  qgemm_fn=None, group=None):
+    def from_full(cls, Q, S, table, table2, num_bits, group_size, template_id, group=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         q, s = shard_rows(Q, S, group_size, world, rank)
-        return cls(q, s, table, table2, num_bits, group_size, template_id, qgemm_fn, group)
+        return cls(q, s, table, table2, num_bits, group_size, template_id, group)
 
     def forward(self, x_shard):
         y = self._local(x_shard)

@@ -114,3 +114,71 @@ def test_tp_rccl_world1(bits, tile_p, dtype_name):
                                                     (3, 32, "bfloat16")])
 def test_tp_rccl_world2(bits, tile_p, dtype_name):
     _run(2, bits, tile_p, dtype_name)
+
+
+def test_simulated_tp8_on_one_gpu():
+    """BASELINE configs[3] without eight GPUs: all 8 column shards of the Llama-3-70B up projection (8192 x 28672)
+    and all 8 row shards of the down projection (28672 x 8192) are cut out of the packed matrices with
+    tp.shard_columns / tp.shard_rows and run through the HIP kernels one after the other on this GPU; the column
+    outputs are concatenated, the row partials are summed IN T in rank order (what the all-reduce does to the
+    kernels' fp16 outputs), and both are compared with the unsharded HIP launch and with the fp32 product of the
+    dequantised matrix (tests/kernel.py:68-71).  Contract: flute/integrations/vllm_utils.py:265-326.
+    Tolerances: rel-Frobenius < 1e-3 (fp16) against the fp32 product - BASELINE's bar - for the column-parallel
+    result and the unsharded launches; < 1.5e-3 for the sum of eight fp16-rounded partials (the reference accepts
+    2.0e-3, tests/kernel.py:12)."""
+    import flute_amd
+    from flute_amd import tp, utils
+    d = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    bits, tile_p, g, dtype, world, M = 4, 32, 64, torch.float16, 8, 2
+    H, F = 8192, 28672
+    tid = min(t for (b, t), c in flute_amd.TEMPLATE_CONFIGS.items() if b == bits and c["TileP"] == tile_p)
+    num_sms = utils.get_device_num_sms(d)
+    ws = utils.get_workspace_streamk(d)
+    table = torch.randn(2 ** bits, device=d).to(dtype)
+    table2 = utils.make_qmap2_from_qmap(table)
+
+    def layer(K, N):
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
+        Q = utils.pack(W, bits, [tid], num_sms)
+        S = (torch.randn(N, K // g, device=d) * 0.1).to(dtype)
+        What = table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T      # [K, N] fp32
+        return W, Q, S, What
+
+    def relerr(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+    # ---- column-parallel up projection: N-shards, no collective ----
+    X = (torch.randn(M, H, device=d) / 10).to(dtype)
+    W, Q, S, What = layer(H, F)
+    want = X.float() @ What
+    full = flute_amd.qgemm(X, Q, S, table, table2, ws, bits, g, tid, num_sms)
+    parts = []
+    for r in range(world):
+        q, s = tp.shard_columns(Q, S, bits, tile_p, world, r)
+        assert q.shape == (bits * (F // world) // 16, H) and s.shape == (F // world, H // g)
+        # the shard is a valid packed matrix of exactly this rank's columns
+        codes = utils.unpack_codes(q, bits, tid)
+        assert torch.equal(codes, W[:, r * F // world:(r + 1) * F // world])
+        parts.append(flute_amd.qgemm(X, q, s, table, table2, ws, bits, g, tid, num_sms))
+    y_col = torch.cat(parts, dim=-1)
+    assert relerr(full, want) < 1e-3 and relerr(y_col, want) < 1e-3
+    assert relerr(y_col, full) < 1e-3
+    del W, Q, S, What, parts
+
+    # ---- row-parallel down projection: K-shards, partials summed in T (the all-reduce) ----
+    X2 = (torch.randn(M, F, device=d) / 10).to(dtype)
+    W, Q, S, What = layer(F, H)
+    want = X2.float() @ What
+    full = flute_amd.qgemm(X2, Q, S, table, table2, ws, bits, g, tid, num_sms)
+    acc = None
+    for r in range(world):
+        q, s = tp.shard_rows(Q, S, g, world, r)
+        assert q.shape == (bits * H // 16, F // world) and s.shape == (H, F // world // g)
+        part = flute_amd.qgemm(X2[:, r * F // world:(r + 1) * F // world].contiguous(), q, s, table, table2, ws, bits, g,
+                               tid, num_sms)
+        assert part.dtype == dtype
+        acc = part if acc is None else acc + part              # fp16 + fp16 -> fp16, as RCCL sums them
+    assert relerr(full, want) < 1e-3
+    assert relerr(acc, want) < 1.5e-3, relerr(acc, want)
+    assert relerr(acc, full) < 1.5e-3

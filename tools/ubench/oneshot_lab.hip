@@ -150,7 +150,8 @@ int main(int argc, char** argv) {
     const int G = K / g, lg = (int)log2((double)g);
     Dev d;
     d.qwords = p.Q.size(); d.swords = p.S.size();
-    d.ncopy = (int)((300ull << 20) / (d.qwords * 4)) + 1;
+    const size_t copies_mb = getenv("LAB_COPIES_MB") ? (size_t)atoi(getenv("LAB_COPIES_MB")) : 300;      // rotating weight copies: total size
+    d.ncopy = (int)((copies_mb << 20) / (d.qwords * 4)) + 1;
     CK(hipMalloc(&d.Q, d.qwords * 4 * d.ncopy)); CK(hipMalloc(&d.S, d.swords * 2 * d.ncopy));
     CK(hipMalloc(&d.X, p.X.size() * 2)); CK(hipMalloc(&d.T2, 1024)); CK(hipMalloc(&d.D, (size_t)M * N * 2 * d.ncopy)); CK(hipMalloc(&d.sink, 64));
     for (int c = 0; c < d.ncopy; ++c) {
