@@ -6,9 +6,9 @@
 namespace flute_amd {
 #define FLUTE_ONE(TP, MB, D, H, O) (OneKernel)qgemv_oneshot_kernel<F16, 2, TP, MB, D, (MB == 4 ? 1 : 2), H, O>
 #define FLUTE_ROW(TP, MB, D) \
-    if (tile_p == TP && mb == MB && depth == D) return had ? FLUTE_ONE(TP, MB, D, true, 1) : FLUTE_ONE(TP, MB, D, false, 1);
+    if (tile_p == TP && mb == MB && depth == D) return had ? FLUTE_ONE(TP, MB, D, true, 33) : FLUTE_ONE(TP, MB, D, false, 33);
 #define FLUTE_ROW_PIPE(TP, D) \
-    if (tile_p == TP && mb == 1 && depth == D && pipe) return had ? FLUTE_ONE(TP, 1, D, true, 17) : FLUTE_ONE(TP, 1, D, false, 17);
+    if (tile_p == TP && mb == 1 && depth == D && pipe) return had ? FLUTE_ONE(TP, 1, D, true, 49) : FLUTE_ONE(TP, 1, D, false, 49);
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe) {
     (void)pipe;
     FLUTE_ROW(32, 1, 4) FLUTE_ROW(32, 1, 8) FLUTE_ROW(32, 2, 4) FLUTE_ROW(32, 2, 8) FLUTE_ROW(32, 4, 4) FLUTE_ROW(32, 4, 8)

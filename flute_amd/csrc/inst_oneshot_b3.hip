@@ -4,7 +4,7 @@
 #include "kernels.h"
 #include "qgemm_oneshot.h"
 namespace flute_amd {
-#define FLUTE_ONE(T, MB, D, H) (OneKernel)qgemv_oneshot_kernel<T, 3, 32, MB, D, 2, H, 1>
+#define FLUTE_ONE(T, MB, D, H) (OneKernel)qgemv_oneshot_kernel<T, 3, 32, MB, D, 2, H, 33>
 #define FLUTE_ROW(MB, D) \
     if (mb == MB && depth == D) { \
         if (dtype == 0) return had ? FLUTE_ONE(F16, MB, D, true) : FLUTE_ONE(F16, MB, D, false); \

@@ -69,9 +69,15 @@ __device__ __forceinline__ u32x2_t lds_hidden64(uint32_t addr) {
     return v;
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
 // OPT bits (development / A-B measurements, tools/ubench/oneshot_lab.hip): 1 = nt on the weight loads,
 // 2 = ablate the lookups (timing floor: stream + prologue only), 8 = wait for every piece before the first
-// lookup (round-2 behaviour), 16 = software-pipelined half-piece loop (4-bit, one row, every wave with D pieces)
+// lookup (round-2 behaviour), 16 = software-pipelined half-piece loop (4-bit, one row, every wave with D pieces),
+// 32 = weight requests interleaved with the table image's LDS work
 template <typename T, int BITS, int TILEP, int MB, int D, int XPR, bool HAD = false, int OPT = 0>
 __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
@@ -179,50 +185,73 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
         qsrd[pl] = make_srd(reinterpret_cast<const char*>(Qp) + (size_t)unit_row<BITS, TILEP>(urow, pl, N) * row_bytes,
                             live ? row_bytes : 0u);
     ring16_t q[D][NP];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
+    constexpr int NX = MB * XPR;
+    constexpr int RUNS = oneshot_lut_runs(BITS);
+    const int nrun = max(0, min(ipw, RUNS - run0));
+    auto issue_piece = [&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
         const uint32_t vo = lane16 + ((i < np) ? (uint32_t)(p0 + i) * 1024u : 0x80000000u);
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             if constexpr (OPT & 1) q[i][pl] = buf_load16_nt(vo, qsrd[pl], 0);
             else q[i][pl] = buf_load16(vo, qsrd[pl], 0);
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    FLUTE_OSTAMP(2);
-
-    // ---- table image: bpermutes in batches of four ahead of their writes ----
-    constexpr int NX = MB * XPR;
-    vm_wait_regs<NX + NSL + D * NP>(lut_v);
-    FLUTE_OSTAMP(3);
-    {
-        constexpr int RUNS = oneshot_lut_runs(BITS);
-        const int nrun = max(0, min(ipw, RUNS - run0));
-        for (int i0 = 0; i0 < nrun; i0 += 4) {
-            uint32_t lo[4], hi[4];
+    };
+    // table image, one batch of (up to) four 1-KiB runs: the entry words come from the lanes that loaded them
+    uint32_t tlo[4], thi[4];
+    auto table_fetch = [&](int i0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if constexpr (BITS == 2) {
-                    const int e = (run0 + i0 + u) * 4 + (lane >> 4);
-                    lo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((e & 15) * 4, (int)lut_v);
-                    hi[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, (int)lut_v);
-                } else {
-                    lo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((((i0 + u) * 8 + (lane >> 3)) & 63) * 4, (int)lut_v);
-                    hi[u] = lo[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i0 + u < nrun) {
-                    uint32_t addr;
-                    if constexpr (BITS == 2) addr = (uint32_t)(run0 + i0 + u) * 1024u + lane16;
-                    else addr = (uint32_t)((run0 + i0 + u) * 8 + (lane >> 3)) * ESTRIDE + (uint32_t)(lane & 7) * 16u;
-                    *reinterpret_cast<uint4*>(smem + addr) = make_uint4(lo[u], hi[u], lo[u], hi[u]);
-                }
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (BITS == 2) {
+                const int e = (run0 + i0 + u) * 4 + (lane >> 4);
+                tlo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((e & 15) * 4, (int)lut_v);
+                thi[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, (int)lut_v);
+            } else {
+                tlo[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((((i0 + u) * 8 + (lane >> 3)) & 63) * 4, (int)lut_v);
+                thi[u] = tlo[u];
             }
         }
+    };
+    auto table_write = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < nrun) {
+                uint32_t addr;
+                if constexpr (BITS == 2) addr = (uint32_t)(run0 + i0 + u) * 1024u + lane16;
+                else addr = (uint32_t)((run0 + i0 + u) * 8 + (lane >> 3)) * ESTRIDE + (uint32_t)(lane & 7) * 16u;
+                *reinterpret_cast<uint4*>(smem + addr) = make_uint4(tlo[u], thi[u], tlo[u], thi[u]);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OPT & 32) {
+        // Interleaved prologue: the weight requests (each stalls the wave ~90 cycles in the texture addresser's
+        // queue) alternate with the table image's LDS work, so that the 32-KB image drains into LDS while the
+        // requests are still going out - the image and the barrier behind it were 1.1 us of a wave's 3.4.
+        constexpr int NB = (BITS == 2) ? 4 : 2;                    // table batches a wave may own (4 runs each)
+        constexpr int QPS = (D + 2 * NB - 1) / (2 * NB);           // pieces issued per table step
+        static_for<D>([&](auto i_tag) { if constexpr (decltype(i_tag)::value < QPS) issue_piece(i_tag); });
+        vm_wait_regs<NX + NSL + (QPS < D ? QPS : D) * NP>(lut_v);
+        FLUTE_OSTAMP(3);
+        static_for<2 * NB>([&](auto step_tag) {
+            constexpr int STEP = decltype(step_tag)::value;
+            constexpr int b = STEP / 2;
+            if (b * 4 < nrun) { if constexpr (STEP % 2 == 0) table_fetch(b * 4); else table_write(b * 4); }
+            static_for<D>([&](auto i_tag) {
+                constexpr int I = decltype(i_tag)::value;
+                if constexpr (I >= (STEP + 1) * QPS && I < (STEP + 2) * QPS) issue_piece(i_tag);
+            });
+        });
+        FLUTE_OSTAMP(2);
+    } else {
+        static_for<D>([&](auto i_tag) { issue_piece(i_tag); });
+        __builtin_amdgcn_sched_barrier(0);
+        FLUTE_OSTAMP(2);
+        vm_wait_regs<NX + NSL + D * NP>(lut_v);
+        FLUTE_OSTAMP(3);
+        for (int i0 = 0; i0 < nrun; i0 += 4) { table_fetch(i0); table_write(i0); }
     }
+    __builtin_amdgcn_sched_barrier(0);
     int* arrive = reinterpret_cast<int*>(smem + red_off);
     if (kw > 1 && tid < upw) arrive[tid] = 0;
     FLUTE_OSTAMP(4);

@@ -166,12 +166,11 @@ int main(int argc, char** argv) {
 
 #define V(name, D_, X_, OPT_, W_, kw_) Variant{name, (OneKernel)qgemv_oneshot_kernel<F16, 4, 32, 1, D_, X_, false, OPT_>, W_, kw_, 0, D_}
     std::vector<Variant> vs = {
-        V("w8_kw2_d4_x2", 4, 2, 0, 8, 2), V("w8_kw2_d4", 4, 1, 0, 8, 2), V("w8_kw2_d4_nt", 4, 1, 1, 8, 2), V("w8_kw2_d4_pipe", 4, 1, 16, 8, 2),
-        V("w8_kw2_d4_pipe_nt", 4, 1, 17, 8, 2), V("w8_kw2_d4_nolookup", 4, 1, 2, 8, 2),
-        V("w4_kw2_d4", 4, 2, 0, 4, 2), V("w4_kw2_d4_pipe_nt", 4, 2, 17, 4, 2),
-        V("w4_kw1_d8", 8, 2, 0, 4, 1), V("w4_kw1_d8_pipe", 8, 2, 16, 4, 1), V("w4_kw1_d8_pipe_nt", 8, 2, 17, 4, 1), V("w4_kw1_d8_nolookup", 8, 2, 2, 4, 1),
-        V("w8_kw1_d8_pipe_nt", 8, 1, 17, 8, 1), V("w8_kw4_d2_nt", 2, 1, 1, 8, 4), V("w8_kw4_d2_pipe_nt", 2, 1, 17, 8, 4),
-        V("w16_kw4_d2_pipe_nt", 2, 1, 17, 16, 4), V("w8_kw4_d4_pipe_nt", 4, 1, 17, 8, 4), V("w16_kw4_d4_nt", 4, 1, 1, 16, 4),
+        V("w4_kw1_d8_pipe_nt", 8, 2, 17, 4, 1), V("w4_kw1_d8_pipe_nt_il", 8, 2, 49, 4, 1), V("w4_kw1_d8_nolookup", 8, 2, 2, 4, 1), V("w4_kw1_d8_nolookup_il", 8, 2, 34, 4, 1),
+        V("w8_kw2_d4_pipe_nt", 4, 1, 17, 8, 2), V("w8_kw2_d4_pipe_nt_il", 4, 1, 49, 8, 2),
+        V("w4_kw2_d4_pipe_nt", 4, 2, 17, 4, 2), V("w4_kw2_d4_pipe_nt_il", 4, 2, 49, 4, 2),
+        V("w8_kw1_d8_pipe_nt", 8, 1, 17, 8, 1), V("w8_kw1_d8_pipe_nt_il", 8, 1, 49, 8, 1),
+        V("w8_kw4_d2_pipe_nt_il", 2, 1, 49, 8, 4), V("w16_kw4_d4_nt_il", 4, 1, 33, 16, 4),
     };
     for (auto& v : vs) {
         const int pk = (npieces + v.kw - 1) / v.kw;
