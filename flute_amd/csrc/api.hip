@@ -709,7 +709,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
         const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
-        uint32_t geo = OneGeo::pack(oa.lg, oa.lkw, oa.upw, oa.pk, oa.ipw, had_log);
+        uint32_t geo = OneGeo::pack(oa.lg, oa.lkw, oa.upw, oa.pk, oa.ipw, had_log, oneshot_x_in_holes(num_bits, p.m_block, K) ? 1 : 0);
         float hs = had_scale;
         uint64_t* stamps = nullptr;
 #ifdef FLUTE_STAMPS

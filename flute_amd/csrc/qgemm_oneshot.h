@@ -29,9 +29,9 @@ namespace flute_amd {
 
 // launch geometry packed into one kernel-argument dword (preloaded)
 struct OneGeo {
-    static constexpr uint32_t pack(int lg, int lkw, int upw, int pk, int ipw, int had_log) {
+    static constexpr uint32_t pack(int lg, int lkw, int upw, int pk, int ipw, int had_log, int xh) {
         return (uint32_t)lg | ((uint32_t)lkw << 4) | ((uint32_t)upw << 8) | ((uint32_t)pk << 13) |
-               ((uint32_t)ipw << 17) | ((uint32_t)had_log << 24);
+               ((uint32_t)ipw << 17) | ((uint32_t)had_log << 24) | ((uint32_t)xh << 28);
     }
 };
 
@@ -45,10 +45,15 @@ __host__ __device__ constexpr int oneshot_lut_runs(int bits) { return bits == 4 
 __host__ __device__ constexpr int oneshot_scale_loads(int bits, int depth) {
     return ((bits == 3 ? 16 : 16 / bits) * depth * 8 / 2 + 63) / 64;
 }
+// 4-bit table image: 256-B entry stride (the lookup address is one v_perm), 128 B of copies per entry - the other
+// 128 B of every slot ("holes", 32 KB in all) hold the staged activations when they fit: 64 k of a row per hole
+__host__ __device__ constexpr bool oneshot_x_in_holes(int bits, int mb, int K) {
+    return bits == 4 && (size_t)mb * ((K + 511) / 512 * 512) * 2 <= 32768;
+}
 // dynamic LDS of a launch (the kernel carves with the same formulas)
 __host__ __device__ constexpr size_t oneshot_lds_bytes(int bits, int mb, int depth, int lg, int K, int waves) {
     const int J = (bits == 3) ? 16 : 16 / bits;
-    return (size_t)oneshot_lut_bytes(bits) + (size_t)mb * ((K + 511) / 512 * 512) * 2 +
+    return (size_t)oneshot_lut_bytes(bits) + (oneshot_x_in_holes(bits, mb, K) ? 0 : (size_t)mb * ((K + 511) / 512 * 512) * 2) +
            (size_t)waves * J * depth * (512 >> lg) * 2 + 128 + (size_t)waves * J * mb * 4;
 }
 
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = geo & 15, lkw = (geo >> 4) & 15, upw = (geo >> 8) & 31, pk = (geo >> 13) & 15;
     const int ipw = (geo >> 17) & 127, had_log = (geo >> 24) & 15;
+    const bool xh = (geo >> 28) & 1;                               // activations in the holes of the table image
     const int kw = 1 << lkw;
     const int nthr = (upw << lkw) * 64;                            // == blockDim.x (an implicit argument: a scalar load away)
     const int ul = wave >> lkw;
@@ -130,7 +136,12 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
     const int gpp = 512 >> lg;                                     // groups per piece
     const int ngm = D * gpp;                                       // groups per wave image
     const uint32_t x_off = LUT;
-    const uint32_t s_off = x_off + (uint32_t)(MB * KX * 2);
+    const uint32_t s_off = x_off + (xh ? 0u : (uint32_t)(MB * KX * 2));
+    // byte address of the 16-B piece `pidx` (8 k each) of staged row m: linear [MB][KX] behind the image, or 64 k per hole
+    auto x_addr = [&](int m, int pidx) -> uint32_t {
+        return xh ? (uint32_t)((m * (KX >> 6) + (pidx >> 3)) * 256 + 128 + (pidx & 7) * 16)
+                  : x_off + (uint32_t)(m * KX * 2 + pidx * 16);
+    };
     const uint32_t s_wave_bytes = (uint32_t)(J * ngm * 2);
     const uint32_t sbase = s_off + (uint32_t)wave * s_wave_bytes;
     const uint32_t red_off = s_off + (uint32_t)(nthr >> 6) * s_wave_bytes;
@@ -258,7 +269,6 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
 
     // ---- activations -> LDS [MB][KX] (zero beyond K); fused pre-rotation: the 64 pieces a wave stages are 512
     // consecutive k of one row = whole Hadamard blocks (K % had == 0, had <= 512; qgemm.cpp:201-244) ----
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem + x_off);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -273,8 +283,7 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
                 uint32_t w[4] = {xv[m][r].x, xv[m][r].y, xv[m][r].z, xv[m][r].w};
                 if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
                 const bool inside = pidx * 8 < K;
-                *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
-                    inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(smem + x_addr(m, pidx)) = inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
             }
         }
         const uint16_t* A = reinterpret_cast<const uint16_t*>(Ap);
@@ -284,8 +293,7 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
             uint32_t w[4] = {t.x, t.y, t.z, t.w};
             if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
             const bool inside = pidx * 8 < K;
-            *reinterpret_cast<uint4*>(xs + (size_t)m * KX + (size_t)pidx * 8) =
-                inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(smem + x_addr(m, pidx)) = inside ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0, 0, 0, 0);
         }
     }
     FLUTE_OSTAMP(6);
@@ -312,7 +320,9 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
     const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
     const int gl = (8 * lane) >> lg;                               // group of the lane's 8 k inside a piece
     const uint32_t s_lane = sbase + (uint32_t)(gl * J) * 2u;
-    const uint32_t x_lane = x_off + lane16 + (uint32_t)p0 * 1024u;
+    const uint32_t x_lane = x_addr(0, p0 * 64 + lane);             // this lane's 16 B of the wave's first piece (row 0)
+    const uint32_t x_pshift = xh ? 11u : 10u;                      // a piece (64 lanes x 16 B) spans 2 KiB of holes / 1 KiB
+    const uint32_t x_row = xh ? (uint32_t)(KX >> 6) * 256u : (uint32_t)KX * 2u;
 
     float acc[J][MB];
 #pragma unroll
@@ -322,12 +332,12 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
 
     auto compute_piece = [&](auto slot_tag) {
         constexpr int i = decltype(slot_tag)::value;
-        const uint32_t xa = x_lane + (uint32_t)i * 1024u;
+        const uint32_t xa = x_lane + ((uint32_t)i << x_pshift);
         const uint32_t sa = s_lane + (uint32_t)(i * gpp * J) * 2u;
         uint32_t xw[MB][4];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            const uint4 t = lds_ld128(xa + (uint32_t)(m * KX * 2));
+            const uint4 t = lds_ld128(xa + (uint32_t)m * x_row);
             xw[m][0] = t.x; xw[m][1] = t.y; xw[m][2] = t.z; xw[m][3] = t.w;
         }
         uint32_t scw[J / 2];                                       // J scales: one vector read (J = 4: 8 B)
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
                 constexpr int I = h / 2, HF = h % 2;
                 if constexpr (HF == 0) {
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[I][0]) : "n"((OPT & 8) ? 0 : (D - 1 - I)) : "memory");
-                    xq[I & 1] = lds_hidden128(x_lane + (uint32_t)I * 1024u);
+                    xq[I & 1] = lds_hidden128(x_lane + ((uint32_t)I << x_pshift));
                     sq[I & 1] = lds_hidden64(s_lane + (uint32_t)(I * gpp * J) * 2u);
                 }
 #pragma unroll

@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
         if (pk > v.depth) { printf("{\"variant\": \"%s\", \"skip\": \"pk %d > depth\"}\n", v.name, pk); continue; }
         const int upw = v.W / v.kw, lkw = (int)log2((double)v.kw);
         const int ipw = (32 + v.W - 1) / v.W;
-        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, ipw, 0);
+        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, ipw, 0, oneshot_x_in_holes(4, 1, K) ? 1 : 0);
         const int grid = (units + upw - 1) / upw;
         const int KX = npieces * 512;
         const size_t lds = oneshot_lds_bytes(4, 1, v.depth, lg, K, v.W); (void)KX;
@@ -292,7 +292,7 @@ int main(int argc, char** argv) {
         const int pk = (npieces + r.kw - 1) / r.kw;
         if (pk > r.depth) continue;
         const int upw = r.W / r.kw, lkw = (int)log2((double)r.kw);
-        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, 0, 0);
+        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, 0, 0, 0);
         const int grid = units / upw;
         void (*fn)(const uint32_t*, uint32_t*, int, uint32_t) =
             r.depth == 4 ? (r.nt ? read_kernel<4, true> : read_kernel<4, false>) : (r.nt ? read_kernel<2, true> : read_kernel<2, false>);
