@@ -508,7 +508,9 @@ __global__ __launch_bounds__(stream_max_threads(BITS, MB, D)) void qgemv_stream_
                     for (int m = 0; m < MB; ++m) rb[wave * (J * MB) + j * MB + m] = tot[j][m];
             }
             int ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // acq_rel: the partial sums above are ordered before the tick, the reads below after it (LDS: a compiler
+            // ordering constraint only)
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
             if (ticket == kw - 1) {
                 for (int t = lane; t < J * MB; t += 64) {
