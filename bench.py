@@ -510,7 +510,9 @@ def main():
             "kernel_us_events": round(ms_per_step * 1e3, 3),
             "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; traffic = "
                     "2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction, MI355X_MICROARCH.md); a pure read of "
-                    "the same bytes in this harness takes 3.16 us (profiles/r01_calibration_stream_read.json)",
+                    "the same bytes, requested the same way, takes 2.8 us per launch and an empty kernel 1.9 us in the stand-alone "
+                    "harness (profiles/r03_calibration_stream_read.json); rocprofv3 kernel-trace serialises replayed graph "
+                    "launches at >= 4 us each, an empty kernel included (profiles/r03_rocprof/lab_traced_vs_untraced.txt)",
         }
         out = {
             "metric": replicas["metric"],

@@ -42,6 +42,8 @@ for case in range(ncases):
         if K % 64:
             K = K * 64 // __import__("math").gcd(K, 64)
     M = rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256, 300, 512, 700, 1024, 2048, 2100])
+    if os.environ.get("FUZZ_DECODE") == "1":                    # decode kernels only (one-shot and ring)
+        M = rng.choice([1, 1, 1, 2, 2, 3, 4])
     torch.manual_seed(case)
     W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=dev)
     S = torch.randn(N, K // g, device=dev).to(dtype)
@@ -59,7 +61,7 @@ for case in range(ncases):
         ran += 1
         maxerr[str(dtype)] = max(maxerr.get(str(dtype), 0.0), err)
         pl = utils.get_plan(M, N, K, bits, g, tid, num_sms, dtype)
-        key = (pl['family'], pl['m_block'], pl['m_tiles'], pl.get('slabs_per_wave'))
+        key = (pl['family'], pl['m_block'], pl['m_tiles'], pl.get('slabs_per_wave'), pl.get('one_shot'))
         fam[key] = fam.get(key, 0) + 1
         tol = 1e-3 if dtype == torch.float16 else 8e-3
         if not err < tol:
@@ -77,8 +79,8 @@ for case in range(ncases):
         fails.append((tag, str(ex)[:200]))
         print("EXC ", tag, str(ex)[:200], flush=True)
 print(f"fuzz: {ran - len(fails)}/{ran} executed cases ok ({ncases - ran} skipped draws) in {time.time() - t0:.1f}s; max rel err {maxerr}")
-print("plans exercised (family, R or rows/pass, MT, SW):", sorted(fam.items()))
+print("plans exercised (family, R or rows/pass, MT, SW, one_shot):", sorted(fam.items()))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump({"cases": ncases, "executed": ran, "fails": fails, "max_rel_err": maxerr,
-           "plans": {str(k): v for k, v in sorted(fam.items())}}, open("gpurun_out/fuzz.json", "w"), indent=1, default=str)
+           "plans": {str(k): v for k, v in sorted(fam.items())}}, open(os.environ.get("FUZZ_OUT", "gpurun_out/fuzz.json"), "w"), indent=1, default=str)
 sys.exit(1 if fails else 0)
