@@ -182,7 +182,8 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
             s.grid = ceil_div(units, s.upw);
             s.lds = oneshot_lds_bytes(bits, mb, D, lg, K, w);
             if (s.lds > (size_t)kMaxLds) continue;
-            s.pipe = (bits == 4 && mb == 1 && s.pk == D && npieces == kw * s.pk && units % s.upw == 0) ? 1 : 0;
+            // pipelined loop: one row, every wave holds D whole pieces
+            s.pipe = (mb == 1 && s.pk == D && npieces == kw * s.pk && units % s.upw == 0 && K % 512 == 0) ? 1 : 0;
             cands.push_back(s);
         }
     }
@@ -702,9 +703,9 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         const int had = had_log > 0 ? 1 : 0;
         if (num_bits == 4) fn = dtype == 0 ? oneshot_kernel_b4_f16(t.tile_p, p.m_block, oa.depth, had, oa.pipe)
                                            : oneshot_kernel_b4_bf16(t.tile_p, p.m_block, oa.depth, had, oa.pipe);
-        else if (num_bits == 2) fn = dtype == 0 ? oneshot_kernel_b2_f16(t.tile_p, p.m_block, oa.depth, had, 0)
-                                                : oneshot_kernel_b2_bf16(t.tile_p, p.m_block, oa.depth, had, 0);
-        else fn = oneshot_kernel_b3(dtype, t.tile_p, p.m_block, oa.depth, had);
+        else if (num_bits == 2) fn = dtype == 0 ? oneshot_kernel_b2_f16(t.tile_p, p.m_block, oa.depth, had, oa.pipe)
+                                                : oneshot_kernel_b2_bf16(t.tile_p, p.m_block, oa.depth, had, oa.pipe);
+        else fn = oneshot_kernel_b3(dtype, t.tile_p, p.m_block, oa.depth, had, oa.pipe);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);

@@ -13,13 +13,13 @@ StreamKernel stream_kernel_b4(int dtype, int tile_p, int mb, int depth, int one_
 StreamKernel stream_kernel_b3(int dtype, int tile_p, int mb, int depth, int one_shot);
 StreamKernel stream_kernel_b2(int dtype, int tile_p, int mb, int depth, int one_shot);
 // one-shot decode kernel (qgemm_oneshot.h): mb rows per pass (1/2/4; b=3: 1/2), depth = pieces per wave (4/8; b=3: 2/4), had = fused
-// Hadamard pre-rotation, pipe = software-pipelined half-piece loop (4-bit, one row, every wave with `depth` pieces)
+// Hadamard pre-rotation, pipe = software-pipelined lookup groups (every wave of the launch holds `depth` whole pieces)
 typedef void (*OneKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, uint64_t*);
 OneKernel oneshot_kernel_b4_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
-OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had);
+OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had, int pipe);
 // block-tiled prefill kernels (qgemm_block2.h / qgemm_block3.h): cfg 4 = 256 x 256 block, cfg 5 = 128 x 256, 8 + RT = skinny 3-bit blocks
 struct BlockArgs;
 typedef void (*BlockKernel)(const BlockArgs);
