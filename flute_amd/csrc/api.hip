@@ -17,7 +17,7 @@
 #include "../../include/flute_amd.h"
 #include "kernels.h"
 #include "qgemm_stream.h"
-#include "qgemm_oneshot.h"
+#include "qgemm_persist.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
 #include "qgemm_block.h"
@@ -144,7 +144,7 @@ bool stream_shape(int bits, int mb, int lg, int units, int krange, int G, bool s
 // keeps the launch at <= 3 workgroups per CU (every workgroup builds its own table image).
 // Template knobs: Stages 2..5 -> rank 0..3; QuantMapMode digit (4-bit ids) 1 / 2 -> D = 4 / 8 only.
 struct OneShape { int W, kw, upw, pk, depth, pipe, ipw, grid; size_t lds; };
-struct OneArgs { int lg, lkw, upw, pk, ipw, depth, pipe; };
+struct OneArgs { int lg, lkw, upw, pk, ipw, depth, pipe, nvis, nch, nwg, nsets; };
 
 int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t, int template_id,
                  const Ovr& ov, flute_plan* p, OneArgs* oa) {
@@ -207,6 +207,67 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
     p->lds_bytes = s.lds; p->lut_copies = 32;
     p->ring_depth = s.depth; p->visits = 1; p->k_chunks = 1; p->one_shot = 1 + s.pipe;
     if (oa) { oa->lg = lg; oa->lkw = ilog2(s.kw); oa->upw = s.upw; oa->pk = s.pk; oa->ipw = s.ipw; oa->depth = s.depth; oa->pipe = s.pipe; }
+    return FLUTE_OK;
+}
+
+// Persistent one-shot kernel (qgemm_persist.h): W <= 8 waves per workgroup, each wave walks `visits` units of `k_chunks`
+// segments (D pieces each; D = 4, 3 bits: 2 - halved while K is not a whole number of segments).  Shapes (W, workgroups
+// per CU) are ranked by what tools/decode_lab.py time_persist_shape measured on the 8192 x 28672-class layers
+// (profiles/r03/persist_lab_shapes.jsonl): first the unit rows the BUSIEST CU decodes (ceil(grid / CUs) x W x visits: the
+// lookups are a per-CU cost - 3-bit layers are bound by it - so a grid of 299 workgroups on 256 CUs costs what 512 would:
+// 42 us against 25.7 on 28672 x 8192 W3), then the launch closest to EIGHT waves per CU (7 - 8 waves per CU x 4 visits
+// beat 14 - 16 x 2 by 4 - 6 %, 4 per CU lose 20 %), then the larger workgroup (fewer table images).
+// Stages 2..5 -> rank 0..3.
+int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t, const Ovr& ov,
+                 flute_plan* p, OneArgs* oa) {
+    if (M != 1 || lg < 6 || ((K >> lg) & 1) || K % 512) return FLUTE_ERR_SHAPE;
+    const int J = (bits == 3) ? 16 : 16 / bits;
+    const int units = N / J;
+    const int npieces = K / 512;
+    int D = (bits == 3) ? 2 : 4;
+    while (D > 2 && npieces % D) D /= 2;
+    if (ov.depth == 2 || (ov.depth == 4 && bits != 3)) D = ov.depth;
+    const int NS = 2;
+    if (npieces % D) return FLUTE_ERR_SHAPE;
+    const int nch = npieces / D;
+    if (nch > 255) return FLUTE_ERR_SHAPE;
+    const int runs = oneshot_lut_runs(bits);
+    const int wcap = std::min(t.threads, 512) / 64;
+    struct Shape { int W, nwg, nvis; long load, off8; size_t lds; };
+    std::vector<Shape> cands;
+    for (int W = wcap; W >= 4; --W) {
+        if (ov.waves > 0 && W != std::min(ov.waves, wcap)) continue;
+        if (bits != 2 && ceil_div(runs, W) > 8) continue;
+        const size_t lds = persist_lds_bytes(bits, D, NS, lg, K, W);
+        if (lds > (size_t)kMaxLds) continue;
+        const int per_cu = std::max(1, std::min((int)((size_t)kMaxLds / lds), 16 / W));
+        for (int c = 1; c <= per_cu; ++c) {
+            if (ov.m_tiles > 0 && c != ov.m_tiles) continue;  // lab: workgroups per CU
+            const int nvis = ceil_div(units, c * num_sms * W);
+            const int nwg = ceil_div(units, W * nvis);
+            bool dup = false;
+            for (const Shape& o : cands) dup = dup || (o.W == W && o.nwg == nwg);
+            if (dup) continue;
+            cands.push_back(Shape{W, nwg, nvis, (long)ceil_div(nwg, num_sms) * W * nvis,
+                                  std::labs((long)ceil_div(nwg, num_sms) * W - 8L), lds});
+        }
+    }
+    if (cands.empty()) return FLUTE_ERR_SHAPE;
+    std::stable_sort(cands.begin(), cands.end(), [](const Shape& a, const Shape& b) {
+        if (a.load != b.load) return a.load < b.load;
+        if (a.off8 != b.off8) return a.off8 < b.off8;
+        return a.W > b.W;
+    });
+    size_t pick = std::min((size_t)std::max(0, t.stages - 2), cands.size() - 1);
+    if (ov.waves > 0 || ov.m_tiles > 0) pick = 0;
+    const Shape& best = cands[pick];
+    p->family = 0;
+    p->m_block = 1; p->waves = best.W; p->kw = 1; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)best.nwg; p->block = (unsigned)(best.W * 64);
+    p->lds_bytes = best.lds; p->lut_copies = 32;
+    p->ring_depth = D; p->visits = best.nvis; p->k_chunks = nch; p->one_shot = 3;
+    if (oa) { oa->lg = lg; oa->lkw = 0; oa->upw = best.W; oa->pk = D; oa->ipw = ceil_div(runs, best.W); oa->depth = D; oa->pipe = 1;
+              oa->nvis = best.nvis; oa->nch = nch; oa->nwg = best.nwg; oa->nsets = NS; }
     return FLUTE_OK;
 }
 
@@ -373,17 +434,28 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
 
     int rc = FLUTE_OK;
     if (family == 0) {
-        // Two decode kernels: the one-shot kernel (qgemm_oneshot.h: non-persistent workgroups, every request up
+        // Three decode kernels: the one-shot kernel (qgemm_oneshot.h: non-persistent workgroups, every request up
         // front) and the persistent ring kernel (qgemm_stream.h).  Forced by override (one_shot 1 / 0; an explicit
         // ring depth or grid K split means the ring kernel) or by the template (4-bit QuantMapMode digit 1, 2:
         // one-shot with 4 / 8 pieces per wave, 3: ring; 2- / 3-bit SMs_Multiple 4: one-shot, 2: ring); automatic:
-        // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup.
+        // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup; one row on larger layers:
+        // the persistent one-shot kernel (qgemm_persist.h; override one_shot = 2).
         int want = ov.one_shot;
         if (want < 0 && (ov.depth > 0 || ov.splitk > 1)) want = 0;
         if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
         if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
         bool taken = false;
-        if (want != 0) {
+        // persistent one-shot kernel: by override, or automatically for one row on layers of >= 64 M weights that give
+        // every CU six whole unit rows (below that the in-workgroup K split of the other two kernels wins:
+        // profiles/r03/persist_lab.txt)
+        const bool persist_auto = want < 0 && M == 1 && (size_t)N * K >= ((size_t)64 << 20) && (long)units >= 6L * num_sms;
+        if (want == 2 || persist_auto) {
+            flute_plan q;
+            memset(&q, 0, sizeof(q));
+            if (plan_persist(bits, lg, M, N, K, num_sms, t, ov, &q, oa) == FLUTE_OK) { *p = q; taken = true; }
+            else if (want == 2) want = 0;
+        }
+        if (!taken && want != 0) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
             if (plan_oneshot(bits, lg, M, N, K, num_sms, t, template_id, ov, &q, oa) == FLUTE_OK &&
@@ -697,6 +769,27 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         }
     }
     const float had_scale = 1.0f / sqrtf((float)(1 << had_log));     // as flute_hadamard: bit-identical results
+
+    if (p.family == 0 && p.one_shot == 3) {
+        const int had = had_log > 0 ? 1 : 0;
+        PersistKernel fn = num_bits == 4 ? persist_kernel_b4(dtype, t.tile_p, oa.depth, oa.nsets, had)
+                           : (num_bits == 2 ? persist_kernel_b2(dtype, t.tile_p, oa.depth, oa.nsets, had)
+                                            : persist_kernel_b3(dtype, t.tile_p, oa.depth, oa.nsets, had));
+        if (!fn) return FLUTE_ERR_SHAPE;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        uint32_t geo = PersistGeo::pack(oa.lg, p.waves, oa.nch, oa.ipw, had_log, oneshot_x_in_holes(num_bits, 1, K) ? 1 : 0);
+        float hs = had_scale;
+        int nvis = oa.nvis, nwg = oa.nwg;
+        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &nvis, &D, &hs, &nwg};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
 
     if (p.family == 0 && p.one_shot) {
         OneKernel fn = nullptr;

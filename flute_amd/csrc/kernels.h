@@ -20,6 +20,11 @@ OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pip
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had, int pipe);
+// persistent one-shot decode kernel (qgemm_persist.h): one row, depth = pieces per segment, nsets = register sets
+typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
+PersistKernel persist_kernel_b4(int dtype, int tile_p, int depth, int nsets, int had);
+PersistKernel persist_kernel_b2(int dtype, int tile_p, int depth, int nsets, int had);
+PersistKernel persist_kernel_b3(int dtype, int tile_p, int depth, int nsets, int had);
 // block-tiled prefill kernels (qgemm_block2.h / qgemm_block3.h): cfg 4 = 256 x 256 block, cfg 5 = 128 x 256, 8 + RT = skinny 3-bit blocks
 struct BlockArgs;
 typedef void (*BlockKernel)(const BlockArgs);

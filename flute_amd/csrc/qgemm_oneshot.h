@@ -62,6 +62,11 @@ __device__ __forceinline__ uint32_t buf_load4_at(uint32_t voff, srd_t srd, uint3
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
     return v;
 }
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
 // hidden LDS reads of the pipelined piece loop (released by the counted lgkmcnt of the lookups behind them)
 __device__ __forceinline__ ring16_t lds_hidden128(uint32_t addr) {
     ring16_t v;
@@ -74,9 +79,130 @@ __device__ __forceinline__ u32x2_t lds_hidden64(uint32_t addr) {
     return v;
 }
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+// The software-pipelined piece loop (one-shot and persistent kernels): D pieces already requested into q[][],
+// YB = loads of this wave that are younger than q's last piece (0 for the one-shot kernel; the next segment's requests
+// in the persistent kernel).  EVERY piece must be a whole, valid piece (the host guarantees it).  A piece is NG groups
+// of 8 lookups: 4 bits: (k-pair words 0,1 | 2,3) x 4 columns; 2 bits: the same with byte lookups (two columns each);
+// 3 bits: k-pair word ww x fields (0..7 | 8..15).  The lookups of group g+1 - and, on a piece boundary, its
+// activation / scale reads (hidden) - are issued before the dot products of group g; LDS returns in order, so "at
+// most NEXT_READS younger operations outstanding" releases group g.
+template <typename T, int BITS, int MB, int D, int YB>
+__device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::NPLANES], uint32_t x_lane, uint32_t x_pshift,
+                                                 uint32_t x_row, uint32_t s_lane, uint32_t s_piece, uint32_t lane_off,
+                                                 float (&acc)[Layout<BITS>::J][MB]) {
+    using NT = Num<T>;
+    constexpr int J = Layout<BITS>::J;
+    constexpr int NP = Layout<BITS>::NPLANES;
+    constexpr int NG = (BITS == 3) ? 8 : 2;                    // groups per piece
+    using look_t = std::conditional_t<BITS == 2, u32x2_t, uint32_t>;
+    look_t v[2][8];
+    ring16_t xq[2][MB];
+    // J scales of a piece: 8 B (J = 4) / 16 B / 32 B - read straight into the registers they are used from (a hidden
+    // read's destination must not be copied before its wait)
+    u32x2_t sq2[2];
+    ring16_t sq4[2][(J + 7) / 8];
+    float al[J][MB];
+    auto issue_group = [&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        constexpr int I = g / NG, GI = g % NG;
+        if constexpr (GI == 0) {
+            if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[I][0]) : "n"((D - 1 - I) * NP + YB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(q[I][0]), "+v"(q[I][1]), "+v"(q[I][2]) : "n"((D - 1 - I) * NP + YB) : "memory");
+#pragma unroll
+            for (int m = 0; m < MB; ++m) xq[I & 1][m] = lds_hidden128(x_lane + ((uint32_t)I << x_pshift) + (uint32_t)m * x_row);
+            const uint32_t sa = s_lane + (uint32_t)I * s_piece;
+            if constexpr (J == 4) sq2[I & 1] = lds_hidden64(sa);
+            else {
+#pragma unroll
+                for (int c = 0; c < J / 8; ++c) sq4[I & 1][c] = lds_hidden128(sa + 16u * c);
+            }
+        }
+        if constexpr (BITS == 4) {
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[g & 1][ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
+        } else if constexpr (BITS == 2) {
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp)
+                    v[g & 1][ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
+        } else {
+            constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
+            const uint32_t w[3] = {q[I][0][ww], q[I][1][ww], q[I][2][ww]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g & 1][j] = lds_lookup32((field<3>(w, j0 + j) << 7) | lane_off);
+        }
+    };
+    auto wait_group = [&](auto g_tag, auto younger_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        constexpr int I = g / NG;
+        look_t(&vv)[8] = v[g & 1];
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7])
+                     : "n"(YOUNGER) : "memory");
+        if constexpr (g % NG == 0) {                           // the piece's activation / scale reads are older than its first group
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { ring16_t& r = xq[I & 1][m]; asm volatile("" : "+v"(r) : : "memory"); }
+            u32x2_t& s2 = sq2[I & 1];
+            if constexpr (J == 4) asm volatile("" : "+v"(s2) : : "memory");
+#pragma unroll
+            for (int c = 0; c < (J + 7) / 8; ++c) { ring16_t& r = sq4[I & 1][c]; if constexpr (J != 4) asm volatile("" : "+v"(r) : : "memory"); }
+        }
+    };
+    issue_group(std::integral_constant<int, 0>{});
+    static_for<NG * D>([&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        constexpr int I = g / NG, GI = g % NG;
+        if constexpr (g + 1 < NG * D) issue_group(std::integral_constant<int, g + 1>{});
+        // what was issued behind group g: the next group's 8 lookups and, on a piece boundary, its MB + ceil(J / 8) reads
+        constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? MB + (J + 7) / 8 : 0) : 0;
+        wait_group(g_tag, std::integral_constant<int, (NEXT_READS < 15 ? NEXT_READS : 15)>{});
+        if constexpr (GI == 0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) al[j][m] = 0.f;
+        }
+        if constexpr (BITS == 4) {
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[g & 1][ww * 4 + j], xq[I & 1][m][2 * GI + ww], al[j][m]);
+        } else if constexpr (BITS == 2) {
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        al[2 * jp][m] = NT::dot2(v[g & 1][ww * 4 + jp].x, xq[I & 1][m][2 * GI + ww], al[2 * jp][m]);
+                        al[2 * jp + 1][m] = NT::dot2(v[g & 1][ww * 4 + jp].y, xq[I & 1][m][2 * GI + ww], al[2 * jp + 1][m]);
+                    }
+        } else {
+            constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) al[j0 + j][m] = NT::dot2(v[g & 1][j], xq[I & 1][m][ww], al[j0 + j][m]);
+        }
+        if constexpr (GI == NG - 1) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                uint32_t w;
+                if constexpr (J == 4) w = sq2[I & 1][j / 2];
+                else w = sq4[I & 1][j / 8][(j % 8) / 2];
+                const float sf = scale_to_float<T>((j & 1) ? (w >> 16) : (w & 0xffffu));
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[j][m] = __builtin_fmaf(al[j][m], sf, acc[j][m]);
+            }
+        }
+    });
 }
 
 // OPT bits (development / A-B measurements, tools/ubench/oneshot_lab.hip): 1 = nt on the weight loads,
@@ -418,123 +544,11 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
     };
 
     if constexpr (PIPE) {
-        // Software-pipelined loop over groups of 8 lookups.  The host launches this variant only when EVERY wave of
-        // the grid holds exactly D pieces (api.hip: plan_oneshot; a run-time fallback to the plain loop would put two
-        // sets of counted waits on the same in-flight registers behind a branch, the arrangement hipcc
-        // mis-schedules - measured: wrong results).  A piece is NG groups: 4 bits: (k-pair words 0,1 | 2,3) x 4 columns;
-        // 2 bits: the same with byte lookups (two columns each); 3 bits: k-pair word ww x fields (0..7 | 8..15).  The
-        // lookups of group g+1 - and, on a piece boundary, its activation / scale reads - are issued before the
-        // dot products of group g; LDS returns in order, so "at most 8 younger operations outstanding" releases group g.
-        constexpr int NG = (BITS == 3) ? 8 : 2;                    // groups per piece
-        using look_t = std::conditional_t<BITS == 2, u32x2_t, uint32_t>;
-        look_t v[2][8];
-        ring16_t xq[2][MB];
-        // J scales of a piece: 8 B (J = 4) / 16 B / 32 B - read straight into the registers they are used from (a hidden
-        // read's destination must not be copied before its wait)
-        u32x2_t sq2[2];
-        ring16_t sq4[2][(J + 7) / 8];
-        float al[J][MB];
-        auto issue_group = [&](auto g_tag) {
-            constexpr int g = decltype(g_tag)::value;
-            constexpr int I = g / NG, GI = g % NG;
-            if constexpr (GI == 0) {
-                if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[I][0]) : "n"((D - 1 - I) * NP) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(q[I][0]), "+v"(q[I][1]), "+v"(q[I][2]) : "n"((D - 1 - I) * NP) : "memory");
-#pragma unroll
-                for (int m = 0; m < MB; ++m) xq[I & 1][m] = lds_hidden128(x_lane + ((uint32_t)I << x_pshift) + (uint32_t)m * x_row);
-                const uint32_t sa = s_lane + (uint32_t)(I * gpp * J) * 2u;
-                if constexpr (J == 4) sq2[I & 1] = lds_hidden64(sa);
-                else {
-#pragma unroll
-                    for (int c = 0; c < J / 8; ++c) sq4[I & 1][c] = lds_hidden128(sa + 16u * c);
-                }
-            }
-            if constexpr (BITS == 4) {
-#pragma unroll
-                for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[g & 1][ww * 4 + j] = lds_lookup32(__builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + j) << 8)));
-            } else if constexpr (BITS == 2) {
-#pragma unroll
-                for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                    for (int jp = 0; jp < 4; ++jp)
-                        v[g & 1][ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
-            } else {
-                constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
-                const uint32_t w[3] = {q[I][0][ww], q[I][1][ww], q[I][2][ww]};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[g & 1][j] = lds_lookup32((field<3>(w, j0 + j) << 7) | lane_off);
-            }
-        };
-        auto wait_group = [&](auto g_tag, auto younger_tag) {
-            constexpr int g = decltype(g_tag)::value;
-            constexpr int YOUNGER = decltype(younger_tag)::value;
-            constexpr int I = g / NG;
-            look_t(&vv)[8] = v[g & 1];
-            asm volatile("s_waitcnt lgkmcnt(%8)"
-                         : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7])
-                         : "n"(YOUNGER) : "memory");
-            if constexpr (g % NG == 0) {                           // the piece's activation / scale reads are older than its first group
-#pragma unroll
-                for (int m = 0; m < MB; ++m) { ring16_t& r = xq[I & 1][m]; asm volatile("" : "+v"(r) : : "memory"); }
-                u32x2_t& s2 = sq2[I & 1];
-                if constexpr (J == 4) asm volatile("" : "+v"(s2) : : "memory");
-#pragma unroll
-                for (int c = 0; c < (J + 7) / 8; ++c) { ring16_t& r = sq4[I & 1][c]; if constexpr (J != 4) asm volatile("" : "+v"(r) : : "memory"); }
-            }
-        };
-        issue_group(std::integral_constant<int, 0>{});
-        static_for<NG * D>([&](auto g_tag) {
-            constexpr int g = decltype(g_tag)::value;
-            constexpr int I = g / NG, GI = g % NG;
-            if constexpr (g + 1 < NG * D) issue_group(std::integral_constant<int, g + 1>{});
-            // what was issued behind group g: the next group's 8 lookups and, on a piece boundary, its MB + ceil(J / 8) reads
-            constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? MB + (J + 7) / 8 : 0) : 0;
-            wait_group(g_tag, std::integral_constant<int, (NEXT_READS < 15 ? NEXT_READS : 15)>{});
-            if constexpr (GI == 0) {
-#pragma unroll
-                for (int j = 0; j < J; ++j)
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) al[j][m] = 0.f;
-            }
-            if constexpr (BITS == 4) {
-#pragma unroll
-                for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[g & 1][ww * 4 + j], xq[I & 1][m][2 * GI + ww], al[j][m]);
-            } else if constexpr (BITS == 2) {
-#pragma unroll
-                for (int ww = 0; ww < 2; ++ww)
-#pragma unroll
-                    for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) {
-                            al[2 * jp][m] = NT::dot2(v[g & 1][ww * 4 + jp].x, xq[I & 1][m][2 * GI + ww], al[2 * jp][m]);
-                            al[2 * jp + 1][m] = NT::dot2(v[g & 1][ww * 4 + jp].y, xq[I & 1][m][2 * GI + ww], al[2 * jp + 1][m]);
-                        }
-            } else {
-                constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) al[j0 + j][m] = NT::dot2(v[g & 1][j], xq[I & 1][m][ww], al[j0 + j][m]);
-            }
-            if constexpr (GI == NG - 1) {
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    uint32_t w;
-                    if constexpr (J == 4) w = sq2[I & 1][j / 2];
-                    else w = sq4[I & 1][j / 8][(j % 8) / 2];
-                    const float sf = scale_to_float<T>((j & 1) ? (w >> 16) : (w & 0xffffu));
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) acc[j][m] = __builtin_fmaf(al[j][m], sf, acc[j][m]);
-                }
-            }
-        });
+        // Software-pipelined loop over groups of 8 lookups (pipelined_pieces).  The host launches this variant only when
+        // EVERY wave of the grid holds exactly D pieces (api.hip: plan_oneshot; a run-time fallback to the plain loop
+        // would put two sets of counted waits on the same in-flight registers behind a branch, the arrangement hipcc
+        // mis-schedules - measured: wrong results).
+        pipelined_pieces<T, BITS, MB, D, 0>(q, x_lane, x_pshift, x_row, s_lane, (uint32_t)(gpp * J) * 2u, lane_off, acc);
     } else {
         // ---- pieces, each released by its own counted wait (loads return in order) ----
         [&]<int... I>(std::integer_sequence<int, I...>) {

@@ -84,7 +84,9 @@ typedef struct flute_plan {
     int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
     int one_shot;        /* decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
                             non-persistent workgroups, every request issued by the prologue, ring_depth = pieces per
-                            wave), 2 = the same with the software-pipelined piece loop */
+                            wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
+                            (qgemm_persist.h: table / activations staged once, every wave walks `visits` units of
+                            `k_chunks` segments of ring_depth pieces, the next segment requested ahead) */
 } flute_plan;
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
@@ -98,7 +100,7 @@ typedef struct flute_plan {
  *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
  *   ring_depth      decode: pieces in flight per wave (ring kernel 2/4; one-shot kernel 4/8, 3-bit 2/4); without
  *                   one_shot = 1 a given depth selects the ring kernel
- *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel */
+ *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 2 persistent one-shot kernel (M = 1) */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;

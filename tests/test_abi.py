@@ -108,8 +108,19 @@ def test_plan_families_and_invariants():
     rc, p = plan(300, 1024, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches
-    rc, p = plan(1, 28672, 8192)
+    rc, p = plan(2, 28672, 8192)
     assert rc == 0 and p.family == 0 and p.waves == 14 and p.kw == 1 and p.visits == 2 and p.one_shot == 0
+    # one row on layers of >= 64 M weights: the persistent one-shot kernel (qgemm_persist.h), ~8 waves per CU, every
+    # unit slot used: 7168 unit rows = 256 workgroups x 7 waves x 4 visits, K = 4 segments of 4 pieces
+    rc, p = plan(1, 28672, 8192)
+    assert rc == 0 and p.family == 0 and p.one_shot == 3 and (p.waves, p.kw, p.grid, p.visits, p.k_chunks, p.ring_depth) == (7, 1, 256, 4, 4, 4)
+    assert p.lds_bytes <= 80 * 1024
+    rc, p = plan(1, 8192, 28672)
+    assert rc == 0 and p.one_shot == 3 and (p.waves, p.grid, p.visits, p.k_chunks) == (8, 256, 1, 14)
+    rc, p = plan(1, 28672, 8192, bits=3, tid=4)
+    assert rc == 0 and p.one_shot == 3 and p.ring_depth == 2 and p.grid * p.waves * p.visits >= 28672 // 16
+    rc, p = plan(1, 8192, 8192, bits=3, tid=4)               # 512 unit rows: too few for a wave per row
+    assert rc == 0 and p.one_shot != 3
     # layers up to 64 M weights: the one-shot kernel (qgemm_oneshot.h); 4096^2 has 8 pieces per unit row: a wave
     # takes all 8 (no cross-wave reduction), every wave is full -> the software-pipelined loop (one_shot 2)
     rc, p = plan(1, 4096, 4096)
@@ -126,19 +137,25 @@ def test_plan_families_and_invariants():
         assert -(-pieces // q.kw) <= q.ring_depth and q.grid == -(-(N // J) // (q.waves // q.kw))
         assert q.lds_bytes <= 160 * 1024
         if q.one_shot == 2:                                   # pipelined loop: every wave holds ring_depth pieces
-            assert bits == 4 and M == 1 and pieces == q.kw * q.ring_depth and (N // J) % (q.waves // q.kw) == 0
+            assert M == 1 and pieces == q.kw * q.ring_depth and (N // J) % (q.waves // q.kw) == 0
     # one_shot = 0 / an explicit ring depth / group size 32 / an odd number of groups (the one-shot kernel reads scale
     # rows as aligned dwords): the persistent ring kernel
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4416, 16, 256, 64 << 20, _lib.Overrides(one_shot=1), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=0), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(ring_depth=4), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 32, 1, 4096, 4096, 16, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
+    # persistent one-shot kernel by override; not for two rows / ragged K / odd group counts (ring kernel instead)
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 3
+    assert q.grid * q.waves * q.visits >= 1024 and q.k_chunks * q.ring_depth == 8
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 2, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4352, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4416, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
     # template knobs: QuantMapMode digit 3 -> ring kernel, 1 / 2 -> one-shot with 4 / 8 pieces per wave
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 19, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 17, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 4
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 18, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 8
     # decode kernel: persistent grid never exceeds the unit groups
-    rc, p = plan(1, 28672, 8192)
+    rc, p = plan(2, 28672, 8192)
     assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4
 
 

@@ -48,7 +48,11 @@ def check():
               # one-shot kernel (qgemm_oneshot.h); combinations a shape cannot take (K too long for kw x depth) are skipped
               dict(one_shot=0), dict(one_shot=1), dict(one_shot=1, ring_depth=4), dict(one_shot=1, ring_depth=8), dict(one_shot=1, ring_depth=2),
               dict(one_shot=1, waves=8), dict(one_shot=1, waves=16), dict(one_shot=1, waves=8, kw=8), dict(one_shot=1, waves=16, kw=4),
-              dict(one_shot=1, waves=12, kw=4), dict(one_shot=1, waves=6, kw=2, ring_depth=4), dict(one_shot=1, waves=5, kw=1)]
+              dict(one_shot=1, waves=12, kw=4), dict(one_shot=1, waves=6, kw=2, ring_depth=4), dict(one_shot=1, waves=5, kw=1),
+              # persistent one-shot kernel (qgemm_persist.h; M = 1 and whole chunks only - the ring kernel otherwise)
+              dict(one_shot=2), dict(one_shot=2, waves=8), dict(one_shot=2, waves=5), dict(one_shot=2, waves=7, ring_depth=4),
+              dict(one_shot=2, waves=4, ring_depth=2), dict(one_shot=2, ring_depth=2, slabs_per_wave=3),
+              dict(one_shot=2, ring_depth=2, slabs_per_wave=4), dict(one_shot=2, waves=6, ring_depth=4, slabs_per_wave=3)]
     for (bits, tile_p, g, dtype, K, N) in cases:
         torch.manual_seed(K + N + bits)
         W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
@@ -176,6 +180,21 @@ def timing_ring():
             time_case(M, N, K, bits, 64, dt, shp, steps=200, tag=tag)
 
 
+def timing_persist():
+    """The persistent one-shot kernel (one_shot = 2; ring_depth = pieces per segment, slabs_per_wave = register sets)
+    against the ring and the one-shot kernel."""
+    for (tag, M, N, K, bits, dt) in (("big W4", 1, 28672, 8192, 4, f16), ("down proj 70B", 1, 8192, 28672, 4, f16), ("big W3", 1, 28672, 8192, 3, bf16),
+                                     ("8192 W3", 1, 8192, 8192, 3, bf16), ("8192 g64", 1, 8192, 8192, 4, f16),
+                                     ("14336x8192", 1, 14336, 8192, 4, f16), ("W2 big", 1, 28672, 8192, 2, f16), ("4096 headline", 1, 4096, 4096, 4, f16),
+                                     ("11008x4096", 1, 11008, 4096, 4, f16), ("4096x11008", 1, 4096, 11008, 4, f16), ("tp shard", 1, 3584, 8192, 4, f16),
+                                     ("W3 4096", 1, 4096, 4096, 3, f16), ("W2 8192", 1, 8192, 8192, 2, f16)):
+        pairs = ((2, 2), (2, 3), (2, 4), (4, 2)) if bits == 3 else ((4, 2), (4, 3), (2, 4), (2, 3), (8, 2))
+        shapes = [dict(one_shot=0), dict(one_shot=1)] + [dict(one_shot=2, ring_depth=dd, slabs_per_wave=ns) for dd, ns in pairs]
+        shapes += [dict(one_shot=2, waves=8, ring_depth=pairs[0][0], slabs_per_wave=2), dict(one_shot=2, waves=4, ring_depth=pairs[0][0], slabs_per_wave=2)]
+        for shp in shapes:
+            time_case(M, N, K, bits, 64, dt, shp, steps=200, tag=tag)
+
+
 t0 = time.time()
 rc = 0
 if "check" in what:
@@ -186,6 +205,16 @@ if "time_small" in what:
     timing(small_only=True)
 if "time_ring" in what:
     timing_ring()
+if "time_persist_shape" in what:
+    for (tag, M, N, K, bits, dt) in (("big W4", 1, 28672, 8192, 4, f16), ("down proj 70B", 1, 8192, 28672, 4, f16), ("big W3", 1, 28672, 8192, 3, bf16),
+                                     ("8192 g64", 1, 8192, 8192, 4, f16), ("14336x8192", 1, 14336, 8192, 4, f16), ("W2 big", 1, 28672, 8192, 2, f16),
+                                     ("8192x14336", 1, 8192, 14336, 4, f16)):
+        for w in (4, 5, 6, 7, 8):
+            for c in (1, 2, 3, 4):
+                if w * c <= 16:
+                    time_case(M, N, K, bits, 64, dt, dict(one_shot=2, waves=w, m_tiles=c), steps=200, tag=tag)
+if "time_persist" in what:
+    timing_persist()
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump([r for r in rows if r.get("kind") != "check" or not r.get("ok")], open("gpurun_out/decode_lab.json", "w"), indent=1)
 print(f"decode_lab done in {time.time() - t0:.1f}s, failures: {rc}")

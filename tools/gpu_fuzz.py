@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flute_amd  # noqa: E402
-from flute_amd import utils  # noqa: E402
+from flute_amd import dev as fdev, utils  # noqa: E402
 
 dev = torch.device("cuda:0")
 num_sms = utils.get_device_num_sms(dev)
@@ -23,6 +23,16 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 fails = []
 ran, maxerr, fam = 0, {}, {}
+# FUZZ_OVR='{"one_shot": 2}': every call carries these launch-plan overrides (flute_overrides fields)
+ovr = fdev.Overrides(**json.loads(os.environ["FUZZ_OVR"])) if os.environ.get("FUZZ_OVR") else None
+
+
+def run(X, Q, S, table, table2, bits, g, tid):
+    if ovr is None:
+        return flute_amd.qgemm(X, Q, S, table, table2, ws, bits, g, tid, num_sms)
+    return fdev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+
+
 t0 = time.time()
 for case in range(ncases):
     bits = rng.choice([4, 4, 4, 2, 3])
@@ -44,6 +54,9 @@ for case in range(ncases):
     M = rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256, 300, 512, 700, 1024, 2048, 2100])
     if os.environ.get("FUZZ_DECODE") == "1":                    # decode kernels only (one-shot and ring)
         M = rng.choice([1, 1, 1, 2, 2, 3, 4])
+    if os.environ.get("FUZZ_DECODE") == "2":                    # one row, K in whole 1024-k steps (persistent one-shot kernel)
+        M = 1
+        K = max(1024, K // 1024 * 1024)
     torch.manual_seed(case)
     W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=dev)
     S = torch.randn(N, K // g, device=dev).to(dtype)
@@ -55,12 +68,12 @@ for case in range(ncases):
     ref = X.float() @ What
     tag = f"case {case}: b{bits} tid{tid} tp{tile_p} g{g} {str(dtype)[6:]} K{K} N{N} M{M}"
     try:
-        out = flute_amd.qgemm(X, Q, S, table, table2, ws, bits, g, tid, num_sms)
+        out = run(X, Q, S, table, table2, bits, g, tid)
         torch.cuda.synchronize()
         err = ((out.float() - ref).norm() / ref.norm()).item()
         ran += 1
         maxerr[str(dtype)] = max(maxerr.get(str(dtype), 0.0), err)
-        pl = utils.get_plan(M, N, K, bits, g, tid, num_sms, dtype)
+        pl = fdev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
         key = (pl['family'], pl['m_block'], pl['m_tiles'], pl.get('slabs_per_wave'), pl.get('one_shot'))
         fam[key] = fam.get(key, 0) + 1
         tol = 1e-3 if dtype == torch.float16 else 8e-3
@@ -71,7 +84,7 @@ for case in range(ncases):
         ks = torch.randint(0, K, (M,), device=dev)
         E = torch.zeros(M, K, device=dev, dtype=dtype)
         E[torch.arange(M, device=dev), ks] = 1
-        o1 = flute_amd.qgemm(E, Q, S, table, table2, ws, bits, g, tid, num_sms)
+        o1 = run(E, Q, S, table, table2, bits, g, tid)
         if not torch.equal(o1.float(), What[ks].to(dtype).float()):
             fails.append((tag, "one-hot"))
             print("FAIL one-hot", tag, utils.get_plan(M, N, K, bits, g, tid, num_sms, dtype), flush=True)
