@@ -445,10 +445,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
         if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
         bool taken = false;
-        // persistent one-shot kernel: by override, or automatically for one row on layers of >= 64 M weights that give
+        // persistent one-shot kernel: by override, or automatically for one row on layers of >= 40 M weights that give
         // every CU six whole unit rows (below that the in-workgroup K split of the other two kernels wins:
         // profiles/r03/persist_lab.txt)
-        const bool persist_auto = want < 0 && M == 1 && (size_t)N * K >= ((size_t)64 << 20) && (long)units >= 6L * num_sms;
+        const bool persist_auto = want < 0 && M == 1 && (size_t)N * K >= ((size_t)40 << 20) && (long)units >= 6L * num_sms;
         if (want == 2 || persist_auto) {
             flute_plan q;
             memset(&q, 0, sizeof(q));

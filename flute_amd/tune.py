@@ -353,7 +353,8 @@ SUPPORTED_SHAPES = [
 EXTRA_SHAPES = [(11008, 4096), (4096, 11008), (3584, 8192)]       # BASELINE.json configs[1], TP-8 shard of configs[3]
 
 
-def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: float = 1e9, rep: int = 40) -> Dict:
+def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: float = 1e9, rep: int = 40,
+               retune: bool = False) -> Dict:
     """flute/tune.py:466-494 (tune_tasks_legacy): time every task once on this GPU, persist the winners."""
     import time
     device = torch.device("cuda")
@@ -373,7 +374,7 @@ def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: f
                     for M in ms:
                         for tile_p in ((None,) if bits == 3 else (None, 32)):
                             k = tuned_key(M, N, K, bits, g, num_sms, dtype, tile_p)
-                            if k in entries:
+                            if k in entries and not retune:         # resume; --retune measures the requested keys again
                                 continue
                             if time.time() - t0 > budget_s:
                                 skipped += 1
@@ -404,6 +405,7 @@ def _main() -> None:
     ap.add_argument("--out", default=TUNED_TABLE_PATH)
     ap.add_argument("--budget-s", type=float, default=1e9)
     ap.add_argument("--rep", type=int, default=40)
+    ap.add_argument("--retune", action="store_true", help="measure keys that already have an entry again (after a kernel change)")
     a = ap.parse_args()
     if a.shapes == "supported":
         shapes = EXTRA_SHAPES + SUPPORTED_SHAPES
@@ -413,7 +415,7 @@ def _main() -> None:
         shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes.split(";")]
     dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}
     r = tune_tasks(shapes, [int(v) for v in a.ms.split(",")], [int(v) for v in a.bits.split(",")],
-                   [int(v) for v in a.groups.split(",")], [dt[v] for v in a.dtypes.split(",")], a.out, a.budget_s, a.rep)
+                   [int(v) for v in a.groups.split(",")], [dt[v] for v in a.dtypes.split(",")], a.out, a.budget_s, a.rep, a.retune)
     print(json.dumps(r))
 
 
