@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "qgemm_stream.h"
 #include "qgemm_persist.h"
+#include "qgemm_skinny.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
 #include "qgemm_block.h"
@@ -34,6 +35,7 @@ Ovr ovr_of(const flute_overrides* o) {
 
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
+constexpr int kFamilySkinny = 5;                // registers-only MFMA kernel for 3 <= M <= 32 (qgemm_skinny.h)
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
@@ -271,6 +273,34 @@ int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute
     return FLUTE_OK;
 }
 
+// Skinny MFMA kernel (qgemm_skinny.h): 4-bit, M <= 16.  A wave = one slab (16 units) x D k-steps, the 4 or 8 waves of a
+// workgroup share the slab's K (no grid-level split: see the kernel's header), so K = 32 D KW with D in {4, 8, 16}.
+int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, flute_plan* p, OneArgs* ka) {
+    if (bits != 4 || M < 1 || M > 16 || lg < 5 || ((K >> lg) & 1) || K % 128) return FLUTE_ERR_SHAPE;
+    const int units = N / 4;
+    if (units % 16) return FLUTE_ERR_SHAPE;
+    if ((size_t)units * K * 2 >= (size_t)0xfffffff0u || (size_t)(M + 16) * K * 2 >= (size_t)0x7ffffff0u) return FLUTE_ERR_SHAPE;
+    const int ksteps = K / 32;
+    int KW = 0, D = 0;
+    for (int kw : {8, 4}) {
+        if (ov.waves > 0 && kw != ov.waves) continue;
+        if (ksteps % kw) continue;
+        const int d = ksteps / kw;
+        if ((d != 4 && d != 8 && d != 16) || ((d * 32) >> lg) > 8) continue;
+        KW = kw; D = d;
+        break;
+    }
+    if (!KW) return FLUTE_ERR_SHAPE;
+    p->family = kFamilySkinny;
+    p->m_block = 1; p->m_tiles = 1; p->slabs_per_wave = 1; p->waves = KW; p->kw = KW; p->splitk = 1;
+    p->k_per_split = K;
+    p->grid = (unsigned)(units / 16); p->block = (unsigned)(KW * 64);
+    p->lds_bytes = skinny_lds_bytes(4, 1, KW); p->lut_copies = 32; p->ring_depth = D; p->visits = 1; p->k_chunks = 1; p->one_shot = 0;
+    p->workspace_needed = 0;
+    if (ka) { memset(ka, 0, sizeof(*ka)); ka->lg = lg; ka->lkw = ilog2(KW); ka->ipw = ceil_div(oneshot_lut_runs(4), KW); ka->depth = D; }
+    return FLUTE_OK;
+}
+
 int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
                 const Ovr& ov, size_t workspace_bytes, flute_plan* p, StreamArgs* sa) {
     const int J = (bits == 3) ? 16 : 16 / bits;
@@ -383,6 +413,19 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
     int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
+    // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), or automatically for 4-bit layers at 3 <= M <= 16 whose
+    // slabs (64 columns) fill 55 .. 100 % of the CUs in ONE round - a workgroup pulls its slab's weights AND all of X
+    // through one CU (~30 GB/s under load), so fewer slabs leave CUs idle and more slabs take a second round; measured
+    // 4096 x 11008 M = 16 17.9 -> 14.1 us, 4096 x 14336 18.2 -> 14.6 (M = 4: 17.5 -> 11.8), 4096 x 8192 10.0 -> 14.0 (not
+    // taken), 4096 x 28672 26.6 -> 27.8 (not taken): profiles/r03/skinny_lab.jsonl.  QuantMapMode digit != 0: never.
+    {
+        const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 &&
+                           K >= 4096 && (long)(units / 16) * 20 >= 11L * num_sms && units / 16 <= num_sms;
+        if (ov.family == kFamilySkinny || auto5) {
+            if (plan_skinny(bits, lg, M, N, K, ov, p, oa) == FLUTE_OK) return FLUTE_OK;
+            memset(p, 0, sizeof(*p));
+        }
+    }
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
     // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks); scale rows in
     // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
@@ -769,6 +812,22 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         }
     }
     const float had_scale = 1.0f / sqrtf((float)(1 << had_log));     // as flute_hadamard: bit-identical results
+
+    if (p.family == kFamilySkinny) {
+        SkinnyKernel fn = skinny_kernel_b4(dtype, t.tile_p, oa.depth);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        uint32_t geo = SkinnyGeo::pack(oa.lg, oa.lkw, oa.ipw);
+        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
 
     if (p.family == 0 && p.one_shot == 3) {
         const int had = had_log > 0 ? 1 : 0;

@@ -1,0 +1,241 @@
+// MFMA kernel for M <= 16 (instantiated: 4 bits, one 16-row tile; written for MT tiles and 2 bits) on layers whose
+// 64-column slabs fill the chip in one round (round 3): the weights go STRAIGHT to the
+// registers of the lanes that feed them to the matrix core, every request of a wave is issued by its prologue.
+// Replaces, for these M, the per-wave kernel of qgemm_tile.h, whose operands travel through wave-private LDS rings
+// (one LDS-DMA per MFMA operand: 7.5 us at M = 16 on 4096 x 4096 against 4.1 us for M = 1).  Reference: the same
+// qgemm_device main loop (flute/csrc/qgemm_kernel.hpp:617-712) and its Stream-K fix-up of partial tiles
+// (tile_scheduler_utils.hpp:460-481), which is what the grid-level K split + last-arriver reduction below stands for.
+//
+// Geometry.  v_mfma_f32_16x16x32: A = weights (lane (u, q): row u = l % 16, k = 8 q .. 8 q + 7), B = activations (lane
+// (j, q): row j of X, the same k), D[u][j] in lane (q, j) as rows 4 q .. 4 q + 3.  A wave owns a SLAB of 16 units (lane
+// l: unit l % 16) and D k-steps (32 k each) of it: per k-step lane (u, q) loads the 16 B of unit row u that hold k-pairs
+// 4 q .. 4 q + 3 of that step - 16 rows x 64 B per request; its four dwords are the four k-pairs, byte t of a dword the
+// pair code of column tile t (2 bits: nibble t), so the J lookups of a dword feed J MFMAs (J column tiles of 16 units)
+// against the SAME activation operand.  Activations: lane (j, q) loads its 16 B of X the same way (rows >= M: zero).
+// Per wave: 1 table + MT D activation + (J / 4) scale + D weight requests, then D x (4 J lookups, 4 J scale
+// multiplications, J MT MFMAs).
+// K is split over the KW waves of a workgroup only (LDS reduction; KW in {4, 8, 16}).  A grid-level split was built and
+// measured (profiles/r03/skinny_lab_gridsplit.jsonl): partial tiles in the workspace and a last-arriver ticket need
+// agent-scope fences, i.e. an L2 write-back per workgroup on this multi-die part - 51 us at 4 splits on 4096 x 4096
+// against 14.5 us unsplit; a second launch costs ~2 us.  So the kernel serves layers with enough slabs for the chip
+// (N >= ~10 K columns at 4 bits) and short K (<= 16 KW k-steps); the rest stays on the per-wave kernel.
+// Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core.
+// Host contract (api.hip: plan_skinny): 2- / 4-bit, K % (32 D) == 0, G even, group size >= 32 and D * 32 / g <= 8,
+// N % (16 J) == 0 (always: TileP >= 32), K / (32 D) <= KW.
+#pragma once
+#include "qgemm_oneshot.h"
+#include "mfma.h"
+
+namespace flute_amd {
+
+struct SkinnyGeo {
+    static constexpr uint32_t pack(int lg, int lkw, int ipw) { return (uint32_t)lg | ((uint32_t)lkw << 4) | ((uint32_t)ipw << 20); }
+};
+__host__ __device__ constexpr size_t skinny_lds_bytes(int bits, int mt, int kw) {
+    const int J = 16 / bits;
+    return (size_t)oneshot_lut_bytes(bits) + (size_t)kw * J * 256 + (size_t)kw * J * mt * 1024;
+}
+
+template <typename T, int BITS, int TILEP, int MT, int D, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
+    const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
+    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp) {
+    static_assert(BITS == 4 || BITS == 2, "3-bit layers take the per-wave kernel");
+    using NT = Num<T>;
+    constexpr int J = 16 / BITS;                                   // column tiles per k-step
+    constexpr int LJ = (BITS == 4) ? 2 : 3;
+    constexpr int NI = J * MT;                                     // 16 x 16 output tiles per wave
+    constexpr int NSL = J / 4;                                     // scale requests per lane
+    constexpr int LUT = oneshot_lut_bytes(BITS);
+    constexpr int NX = MT * D;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();                  // v_perm-built table addresses are absolute
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = geo & 15, lkw = (geo >> 4) & 15, ipw = (geo >> 20) & 127;
+    const int KW = 1 << lkw;
+    const int u = lane & 15, q = lane >> 4;
+    const int units = N >> LJ;
+    const int slabs = units >> 4;
+    const int slab = (int)blockIdx.x;
+    const int G = K >> lg;
+    const int ksteps = K >> 5;
+    const int kp = wave;                                           // this wave's K part: k-steps [kp D, kp D + D)
+    const bool active = kp * D < ksteps;                           // K % (32 D) == 0: a part is whole or empty
+    const uint32_t row_bytes = (uint32_t)K * 2u;
+    const uint32_t kbyte0 = (uint32_t)(kp * D) * 64u + (uint32_t)q * 16u;      // this lane's 16 B of k-step 0 inside a row
+    const uint32_t dead = 0x80000000u;
+
+    // LDS carve (skinny_lds_bytes)
+    const uint32_t s_off = LUT;
+    const uint32_t simg = s_off + (uint32_t)wave * (J * 256);
+    const uint32_t red_off = s_off + (uint32_t)KW * (J * 256);
+
+    // ---- requests, oldest first: table word, activations, scale words, weights ----
+    const srd_t lut_srd = make_srd(QM2, (uint32_t)(4 << (2 * BITS)));
+    const int run0 = wave * ipw;
+    uint32_t lut_v;
+    if constexpr (BITS == 2) lut_v = buf_load4((uint32_t)(lane & 15) * 4u, lut_srd);
+    else lut_v = buf_load4((uint32_t)(run0 * 8 + lane) * 4u, lut_srd);
+
+    // scale words: lane (u, q) fetches 8 groups (16 B) of column tile t = q (+ 4) of its unit, from the even group at or
+    // below the wave's first one (G even: the address is dword-aligned; a misaligned buffer load reads aligned-down)
+    const int unit = slab * 16 + u;
+    const int col0 = unit_col0<BITS, TILEP>(unit);
+    const int g0 = (kp * D * 32) >> lg;
+    const int g0e = g0 & ~1;
+    const srd_t s_srd = make_srd(Sp, (uint32_t)min((size_t)N * G * 2, (size_t)0xfffffff0u));
+    ring16_t sv[NSL];
+#pragma unroll
+    for (int r = 0; r < NSL; ++r) {
+        const int t = q + 4 * r;
+        sv[r] = buf_load16(active ? (uint32_t)(((size_t)(col0 + t * TILEP) * G + g0e) * 2) : dead, s_srd, 0);
+    }
+
+    // k-step i: its weight piece, then its activation pieces (the loads of a wave return in order: step i is released
+    // by ONE counted wait while the later steps are still in flight)
+    const srd_t x_srd = make_srd(Ap, (uint32_t)min((size_t)M * K * 2, (size_t)0xfffffff0u));
+    const srd_t q_srd = make_srd(Qp, (uint32_t)min((size_t)units * row_bytes, (size_t)0xfffffff0u));
+    ring16_t w[D];
+    ring16_t xv[MT][D];
+    {
+        const uint32_t wbase = active ? (uint32_t)unit * row_bytes + kbyte0 : dead;
+        uint32_t xbase[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xbase[mt] = (active && mt * 16 + u < M) ? (uint32_t)(mt * 16 + u) * row_bytes + kbyte0 : dead;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            w[i] = buf_load16(wbase + (uint32_t)i * 64u, q_srd, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xv[mt][i] = buf_load16(xbase[mt] + (uint32_t)i * 64u, x_srd, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- table image (as qgemm_oneshot.h) ----
+    vm_wait_regs<NSL + D + NX>(lut_v);
+    {
+        constexpr int RUNS = oneshot_lut_runs(BITS);
+        constexpr int ESTRIDE = 256;
+        const uint32_t lane16 = (uint32_t)lane * 16u;
+        const int nrun = max(0, min(ipw, RUNS - run0));
+        for (int i0 = 0; i0 < nrun; i0 += 4) {
+            uint32_t tlo[4], thi[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                if constexpr (BITS == 2) {
+                    const int e = (run0 + i0 + uu) * 4 + (lane >> 4);
+                    tlo[uu] = (uint32_t)__builtin_amdgcn_ds_bpermute((e & 15) * 4, (int)lut_v);
+                    thi[uu] = (uint32_t)__builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, (int)lut_v);
+                } else {
+                    tlo[uu] = (uint32_t)__builtin_amdgcn_ds_bpermute((((i0 + uu) * 8 + (lane >> 3)) & 63) * 4, (int)lut_v);
+                    thi[uu] = tlo[uu];
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                if (i0 + uu < nrun) {
+                    uint32_t addr;
+                    if constexpr (BITS == 2) addr = (uint32_t)(run0 + i0 + uu) * 1024u + lane16;
+                    else addr = (uint32_t)((run0 + i0 + uu) * 8 + (lane >> 3)) * ESTRIDE + (uint32_t)(lane & 7) * 16u;
+                    *reinterpret_cast<uint4*>(smem + addr) = make_uint4(tlo[uu], thi[uu], tlo[uu], thi[uu]);
+                }
+            }
+        }
+    }
+    // ---- scale image of the wave: [tile t][unit u] x 8 groups (16 B) ----
+#pragma unroll
+    for (int r = 0; r < NSL; ++r) {
+        vm_wait_regs<D + NX>(sv[r]);
+        *reinterpret_cast<uint4*>(smem + simg + (uint32_t)(((q + 4 * r) * 16 + u) * 16)) = make_uint4(sv[r].x, sv[r].y, sv[r].z, sv[r].w);
+    }
+    __syncthreads();                                               // table image visible to every wave
+
+    const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
+    f32x4_t acc[NI];
+#pragma unroll
+    for (int e = 0; e < NI; ++e) acc[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (active) {
+        static_for<D>([&](auto i_tag) {
+            constexpr int I = decltype(i_tag)::value;
+            if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"((D - 1 - I) * 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"((D - 1 - I) * 3) : "memory");
+            // this k-step's group: scales of the lane's J columns
+            const uint32_t goff = (uint32_t)((((kp * D + I) * 32) >> lg) - g0e) * 2u;
+            uint32_t sc[J];
+#pragma unroll
+            for (int t = 0; t < J; ++t) sc[t] = lds_ld16(simg + (uint32_t)((t * 16 + u) * 16) + goff);
+            const uint32_t wd[4] = {w[I].x, w[I].y, w[I].z, w[I].w};
+            u32x4_t a[J];
+            if constexpr (BITS == 4) {
+                uint32_t v[16];
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        v[ww * 4 + t] = lds_lookup32(__builtin_amdgcn_perm(wd[ww], lane_off, 0x0c0c0400u | ((4u + t) << 8)));
+                lds_lookup_wait(v);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) a[t][ww] = NT::mul_scale(v[ww * 4 + t], sc[t]);
+            } else {
+                u32x2_t v[16];
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp)
+                        v[ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(wd[ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
+                lds_lookup_wait(v);
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        a[2 * jp][ww] = NT::mul_scale(v[ww * 4 + jp].x, sc[2 * jp]);
+                        a[2 * jp + 1][ww] = NT::mul_scale(v[ww * 4 + jp].y, sc[2 * jp + 1]);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4_t b = {xv[mt][I].x, xv[mt][I].y, xv[mt][I].z, xv[mt][I].w};
+#pragma unroll
+                for (int t = 0; t < J; ++t) acc[t * MT + mt] = Mfma<T>::run(a[t], b, acc[t * MT + mt]);
+            }
+        });
+    } else {
+        // nothing of this wave's is in range: its requests read nothing; drain them before the registers die
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- K reduction inside the workgroup: tile e is summed by wave e % KW, in wave order ----
+    float4* red = reinterpret_cast<float4*>(smem + red_off);
+#pragma unroll
+    for (int e = 0; e < NI; ++e) red[(wave * NI + e) * 64 + lane] = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+    __syncthreads();
+    uint16_t* Dout = reinterpret_cast<uint16_t*>(Dp);
+    // tile e = (t, mt): lane (q, j) holds rows (units) 4 q .. 4 q + 3 of X row mt 16 + j: four consecutive columns
+    auto store_tile = [&](int e, float4 s) {
+        const int t = e / MT, mt = e % MT;
+        const int row = mt * 16 + u;
+        if (row < M) {
+            const int col = unit_col0<BITS, TILEP>(slab * 16 + 4 * q) + t * TILEP;
+            ushort4 o;
+            o.x = NT::from_float(s.x); o.y = NT::from_float(s.y); o.z = NT::from_float(s.z); o.w = NT::from_float(s.w);
+            *reinterpret_cast<ushort4*>(Dout + (size_t)row * N + col) = o;
+        }
+    };
+    for (int e = wave; e < NI; e += KW) {
+        float4 s = red[e * 64 + lane];
+        for (int ww = 1; ww < KW; ++ww) {
+            const float4 p = red[(ww * NI + e) * 64 + lane];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        store_tile(e, s);
+    }
+}
+
+}  // namespace flute_amd

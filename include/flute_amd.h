@@ -67,7 +67,9 @@ typedef struct flute_template_info {
 typedef struct flute_plan {
     int family;          /* 0 = decode (GEMV kernels, M<=4; 3 bits: M<=2; see one_shot), 2 = MFMA kernel with
                             LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
-                            (4-bit, enough 128/256 x 256 output blocks to fill the chip) */
+                            (4-bit, enough 128/256 x 256 output blocks to fill the chip), 5 = skinny MFMA kernel
+                            (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
+                            slabs fill 55..100 % of the CUs; weights and activations straight to registers) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
@@ -91,7 +93,8 @@ typedef struct flute_plan {
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
- *   family          0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
+ *   family          5 skinny MFMA kernel (4-bit, M <= 16; waves 4 / 8 picks the in-workgroup K split);
+ *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
  *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)

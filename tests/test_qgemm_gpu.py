@@ -279,6 +279,54 @@ def test_persistent_oneshot_kernel(env):
     assert plan["one_shot"] == 3 and plan["waves"] * plan["grid"] <= 8 * env.num_sms, plan
 
 
+def test_skinny_mfma_kernel(env):
+    """The skinny MFMA kernel (qgemm_skinny.h; override family 5, automatic for 4-bit layers at 3 <= M <= 16 whose
+    64-column slabs fill the chip in one round): every k-step depth (K = 32 x depth x waves), 4 and 8 waves, both dtypes
+    and TileP, group sizes 32 .. 256, every M up to 16 (rows beyond M read as zero) - against the oracle, one-hot rows
+    bit-exact (w^ = round_T(lut * s), the reference's contract)."""
+    from flute_amd import dev
+    d = env.dev
+    cases = [
+        # bits, tile_p, g, dtype, K, N
+        (4, 32, 64, torch.float16, 4096, 1024), (4, 64, 128, torch.bfloat16, 2048, 1024), (4, 32, 256, torch.float16, 4096, 256),
+        (4, 32, 32, torch.bfloat16, 1024, 256), (4, 64, 64, torch.float16, 512, 512), (4, 32, 128, torch.float16, 1024, 11008),
+    ]
+    for (bits, tile_p, g, dtype, K, N) in cases:
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 85 + N % 7)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for M in (1, 3, 7, 16):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            ref = X.float() @ What
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            ran = 0
+            for waves in (8, 4):
+                ovr = dev.Overrides(family=5, waves=waves)
+                plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
+                if plan["family"] != 5:                      # K / (32 waves) is not 4, 8 or 16 (or too many groups per wave)
+                    continue
+                ran += 1
+                assert plan["ring_depth"] * plan["waves"] * 32 == K and plan["grid"] == N // 64 and plan["splitk"] == 1
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert rel_err(out, ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, waves)
+                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert torch.equal(out1, ref1), (bits, tile_p, g, dtype, K, N, M, waves)
+            assert ran, (K, g)
+    # taken automatically on the Llama-2 / Llama-3 8B MLP widths; same results as the per-wave kernel within tolerance
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 4096, 11008
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=5)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    X = (torch.randn(16, K) / 100).to(dtype)
+    assert dev.get_plan(16, N, K, bits, g, tid, env.num_sms, dtype)["family"] == 5
+    a = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+    b = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=2))
+    assert rel_err(a, b.float()) < 5e-4
+
+
 def test_decode_chunked_activations(env):
     """K ranges whose activations do not fit in LDS at once are staged in chunks (M = 4, K = 28672: 224 KB)."""
     from flute_amd import dev
