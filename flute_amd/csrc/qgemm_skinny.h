@@ -19,6 +19,10 @@
 // agent-scope fences, i.e. an L2 write-back per workgroup on this multi-die part - 51 us at 4 splits on 4096 x 4096
 // against 14.5 us unsplit; a second launch costs ~2 us.  So the kernel serves layers with enough slabs for the chip
 // (N >= ~10 K columns at 4 bits) and short K (<= 16 KW k-steps); the rest stays on the per-wave kernel.
+// Where the time goes (4096 x 14336, M = 16, 224 workgroups, 14.5 us; builds with parts removed, profiles/r03/
+// skinny_ablation.txt): launch + table image + reduction 4.2 us, the requests of a workgroup (131 KB of weights + 128 KB
+// of X through ONE CU) 4.1 us, the k-steps 3.9 us (as many lookups per CU as the M = 1 kernels), and they do not overlap:
+// every CU holds one workgroup whose waves all wait for the same stream.
 // Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core.
 // Host contract (api.hip: plan_skinny): 2- / 4-bit, K % (32 D) == 0, G even, group size >= 32 and D * 32 / g <= 8,
 // N % (16 J) == 0 (always: TileP >= 32), K / (32 D) <= KW.
@@ -33,6 +37,8 @@ struct SkinnyGeo {
 };
 __host__ __device__ constexpr size_t skinny_lds_bytes(int bits, int mt, int kw) {
     const int J = 16 / bits;
+    // > 80 KB on purpose: one workgroup per CU (two resident workgroups share a CU's memory path and were measured
+    // slower - 4096 x 14336 M = 16: 15.7 against 14.5 us - when the grid has fewer workgroups than the chip has CUs)
     return (size_t)oneshot_lut_bytes(bits) + (size_t)kw * J * 256 + (size_t)kw * J * mt * 1024;
 }
 
@@ -40,7 +46,7 @@ template <typename T, int BITS, int TILEP, int MT, int D, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp) {
-    static_assert(BITS == 4 || BITS == 2, "3-bit layers take the per-wave kernel");
+    static_assert(BITS == 4, "2- and 3-bit layers take the per-wave kernel");
     using NT = Num<T>;
     constexpr int J = 16 / BITS;                                   // column tiles per k-step
     constexpr int LJ = (BITS == 4) ? 2 : 3;
@@ -160,50 +166,57 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     for (int e = 0; e < NI; ++e) acc[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if (active) {
-        static_for<D>([&](auto i_tag) {
-            constexpr int I = decltype(i_tag)::value;
-            if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"((D - 1 - I) * 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"((D - 1 - I) * 3) : "memory");
-            // this k-step's group: scales of the lane's J columns
-            const uint32_t goff = (uint32_t)((((kp * D + I) * 32) >> lg) - g0e) * 2u;
-            uint32_t sc[J];
+        // Software-pipelined k-steps (as pipelined_pieces of the decode kernels).  A k-step is two groups of 8 lookups
+        // (column tiles 0, 1 | 2, 3 x the lane's four k-pairs); the lookups of group g + 1 - and, on a k-step boundary,
+        // its J scale reads (hidden) behind the counted wait for its weight / activation pieces - are issued before
+        // the scaling and the MFMAs of group g; LDS returns in order, so "at most NEXT_READS younger operations
+        // outstanding" releases group g.
+        static_assert(BITS == 4 && J == 4, "the skinny kernel is instantiated for 4-bit layers");
+        constexpr int NG = 2;
+        uint32_t v[2][8];
+        uint32_t sc[2][J];
+        auto issue_group = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            constexpr int I = g / NG, GI = g % NG;
+            if constexpr (GI == 0) {
+                if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"((D - 1 - I) * 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"((D - 1 - I) * 3) : "memory");
+                const uint32_t sa = simg + (uint32_t)(u * 16) + (uint32_t)((((kp * D + I) * 32) >> lg) - g0e) * 2u;
 #pragma unroll
-            for (int t = 0; t < J; ++t) sc[t] = lds_ld16(simg + (uint32_t)((t * 16 + u) * 16) + goff);
+                for (int t = 0; t < J; ++t) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(sc[I & 1][t]) : "v"(sa), "n"(t * 256) : "memory");
+            }
             const uint32_t wd[4] = {w[I].x, w[I].y, w[I].z, w[I].w};
-            u32x4_t a[J];
-            if constexpr (BITS == 4) {
-                uint32_t v[16];
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww)
+            for (int ww = 0; ww < 4; ++ww)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        v[ww * 4 + t] = lds_lookup32(__builtin_amdgcn_perm(wd[ww], lane_off, 0x0c0c0400u | ((4u + t) << 8)));
-                lds_lookup_wait(v);
+                for (int tt = 0; tt < 2; ++tt)
+                    v[g & 1][ww * 2 + tt] = lds_lookup32(__builtin_amdgcn_perm(wd[ww], lane_off, 0x0c0c0400u | ((4u + 2 * GI + tt) << 8)));
+        };
+        issue_group(std::integral_constant<int, 0>{});
+        static_for<NG * D>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            constexpr int I = g / NG, GI = g % NG;
+            if constexpr (g + 1 < NG * D) issue_group(std::integral_constant<int, g + 1>{});
+            constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? J : 0) : 0;
+            uint32_t(&vv)[8] = v[g & 1];
+            asm volatile("s_waitcnt lgkmcnt(%8)"
+                         : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7])
+                         : "n"(NEXT_READS) : "memory");
+            if constexpr (GI == 0) {                               // the k-step's scale reads are older than its first group
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) a[t][ww] = NT::mul_scale(v[ww * 4 + t], sc[t]);
-            } else {
-                u32x2_t v[16];
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww)
-#pragma unroll
-                    for (int jp = 0; jp < 4; ++jp)
-                        v[ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(wd[ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
-                lds_lookup_wait(v);
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        a[2 * jp][ww] = NT::mul_scale(v[ww * 4 + jp].x, sc[2 * jp]);
-                        a[2 * jp + 1][ww] = NT::mul_scale(v[ww * 4 + jp].y, sc[2 * jp + 1]);
-                    }
+                for (int t = 0; t < J; ++t) { uint32_t& r = sc[I & 1][t]; asm volatile("" : "+v"(r) : : "memory"); }
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const u32x4_t b = {xv[mt][I].x, xv[mt][I].y, xv[mt][I].z, xv[mt][I].w};
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * GI + tt;
+                u32x4_t a;
 #pragma unroll
-                for (int t = 0; t < J; ++t) acc[t * MT + mt] = Mfma<T>::run(a[t], b, acc[t * MT + mt]);
+                for (int ww = 0; ww < 4; ++ww) a[ww] = NT::mul_scale(v[g & 1][ww * 2 + tt], sc[I & 1][t]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4_t b = {xv[mt][I].x, xv[mt][I].y, xv[mt][I].z, xv[mt][I].w};
+                    acc[t * MT + mt] = Mfma<T>::run(a, b, acc[t * MT + mt]);
+                }
             }
         });
     } else {
