@@ -413,14 +413,19 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
     int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
-    // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), or automatically for 4-bit layers at 3 <= M <= 16 whose
-    // slabs (64 columns) fill 55 .. 100 % of the CUs in ONE round - a workgroup pulls its slab's weights AND all of X
-    // through one CU (~30 GB/s under load), so fewer slabs leave CUs idle and more slabs take a second round; measured
-    // 4096 x 11008 M = 16 17.9 -> 14.1 us, 4096 x 14336 18.2 -> 14.6 (M = 4: 17.5 -> 11.8), 4096 x 8192 10.0 -> 14.0 (not
-    // taken), 4096 x 28672 26.6 -> 27.8 (not taken): profiles/r03/skinny_lab.jsonl.  QuantMapMode digit != 0: never.
+    // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), by template (4-bit QuantMapMode digit 3 at M <= 16, where
+    // the digit's other meaning - two slabs per wave - does not exist; digit 2: never), or automatically (digit 0) for
+    // 3 <= M <= 16 on layers whose slabs (64 columns) fill 55 .. 100 % of the CUs in ONE round, or at least 1.7 rounds - a
+    // workgroup pulls its slab's weights AND all of X through one CU, so fewer slabs leave CUs idle and a few more than
+    // one round wait for a second.  Measured (profiles/r03/skinny_lab.jsonl, M = 16, us, per-wave kernel -> skinny):
+    // 4096 x 11008 17.9 -> 12.0, 4096 x 14336 18.3 -> 12.6 (M = 4: 17.6 -> 11.8), 4096 x 28672 26.6 -> 23.3, 4096 x 6144
+    // 13.1 -> 11.7, 2048 x 8192 7.6 -> 7.0; 4096 x 8192 10.0 -> 11.8 and 4096^2 7.6 -> 11.6 (not taken).
     {
-        const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 &&
-                           K >= 4096 && (long)(units / 16) * 20 >= 11L * num_sms && units / 16 <= num_sms;
+        const int q4 = (bits == 4) ? template_id % 4 : -1;
+        const long slabs5 = units / 16;
+        const bool fill5 = (slabs5 * 20 >= 11L * num_sms && slabs5 <= num_sms) || slabs5 * 10 >= 17L * num_sms;
+        const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 &&
+                           ((q4 == 0 && K >= 4096 && fill5) || q4 == 3);
         if (ov.family == kFamilySkinny || auto5) {
             if (plan_skinny(bits, lg, M, N, K, ov, p, oa) == FLUTE_OK) return FLUTE_OK;
             memset(p, 0, sizeof(*p));
@@ -820,7 +825,11 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
         const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
         uint32_t geo = SkinnyGeo::pack(oa.lg, oa.lkw, oa.ipw);
-        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D};
+        uint64_t* stamps = nullptr;
+#ifdef FLUTE_STAMPS
+        if (workspace && workspace_bytes >= (size_t)p.grid * p.waves * 128) stamps = reinterpret_cast<uint64_t*>(workspace);
+#endif
+        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D, &stamps};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
             hipSuccess) {
             (void)hipGetLastError();

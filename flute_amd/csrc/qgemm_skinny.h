@@ -22,7 +22,11 @@
 // Where the time goes (4096 x 14336, M = 16, 224 workgroups, 14.5 us; builds with parts removed, profiles/r03/
 // skinny_ablation.txt): launch + table image + reduction 4.2 us, the requests of a workgroup (131 KB of weights + 128 KB
 // of X through ONE CU) 4.1 us, the k-steps 3.9 us (as many lookups per CU as the M = 1 kernels), and they do not overlap:
-// every CU holds one workgroup whose waves all wait for the same stream.
+// every CU holds one workgroup whose waves all wait for the same stream.  Stamps (profiles/r03/skinny_stamps.json): the
+// 34 requests of a wave take 9 K cycles to issue, 18 K for the second wave of a SIMD - a request that touches 16 half
+// cache lines costs ~60 cycles of the CU's addresser; asking for the same bytes line-coalesced (lane l: chunk l % 4 of row
+// l / 4) and moving them to the operand lanes with ds_bpermute was measured slower (16.7 us: the requests still cost
+// ~55 cycles - the cost is per line touched - and the k-steps grow from 520 to 850 cycles).
 // Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core.
 // Host contract (api.hip: plan_skinny): 2- / 4-bit, K % (32 D) == 0, G even, group size >= 32 and D * 32 / g <= 8,
 // N % (16 J) == 0 (always: TileP >= 32), K / (32 D) <= KW.
@@ -45,7 +49,7 @@ __host__ __device__ constexpr size_t skinny_lds_bytes(int bits, int mt, int kw) 
 template <typename T, int BITS, int TILEP, int MT, int D, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
-    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp) {
+    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp, uint64_t* __restrict__ stamps) {
     static_assert(BITS == 4, "2- and 3-bit layers take the per-wave kernel");
     using NT = Num<T>;
     constexpr int J = 16 / BITS;                                   // column tiles per k-step
@@ -57,6 +61,15 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();                  // v_perm-built table addresses are absolute
+#ifdef FLUTE_STAMPS
+    uint64_t stamp[16];
+    for (int i = 0; i < 16; ++i) stamp[i] = 0;
+    stamp[0] = wall_clock64();                                    // 100 MHz, chip-wide
+    stamp[1] = __builtin_amdgcn_s_memtime();                       // shader cycles: the phases of this wave
+#define FLUTE_KSTAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FLUTE_KSTAMP(i)
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,22 +120,27 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     const srd_t q_srd = make_srd(Qp, (uint32_t)min((size_t)units * row_bytes, (size_t)0xfffffff0u));
     ring16_t w[D];
     ring16_t xv[MT][D];
-    {
-        const uint32_t wbase = active ? (uint32_t)unit * row_bytes + kbyte0 : dead;
-        uint32_t xbase[MT];
+    // The requests of the first PRE k-steps go out before the table image is built (their HBM latency hides it), the
+    // rest after the barrier: a request that touches 16 half cache lines keeps the SIMD's memory issue busy for ~270
+    // cycles (stamps), so the second wave of a SIMD issues long after the first - which meanwhile decodes.
+    constexpr int AHEAD = D / 2;
+    constexpr int PRE = AHEAD < 2 ? AHEAD : 2;
+    const uint32_t wbase = active ? (uint32_t)unit * row_bytes + kbyte0 : dead;
+    uint32_t xbase[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xbase[mt] = (active && mt * 16 + u < M) ? (uint32_t)(mt * 16 + u) * row_bytes + kbyte0 : dead;
+    for (int mt = 0; mt < MT; ++mt) xbase[mt] = (active && mt * 16 + u < M) ? (uint32_t)(mt * 16 + u) * row_bytes + kbyte0 : dead;
+    auto issue_step = [&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        w[i] = buf_load16(wbase + (uint32_t)i * 64u, q_srd, 0);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            w[i] = buf_load16(wbase + (uint32_t)i * 64u, q_srd, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xv[mt][i] = buf_load16(xbase[mt] + (uint32_t)i * 64u, x_srd, 0);
-        }
-    }
+        for (int mt = 0; mt < MT; ++mt) xv[mt][i] = buf_load16(xbase[mt] + (uint32_t)i * 64u, x_srd, 0);
+    };
+    static_for<PRE>(issue_step);
     __builtin_amdgcn_sched_barrier(0);
+    FLUTE_KSTAMP(2);
 
     // ---- table image (as qgemm_oneshot.h) ----
-    vm_wait_regs<NSL + D + NX>(lut_v);
+    vm_wait_regs<NSL + PRE * (1 + MT)>(lut_v);
     {
         constexpr int RUNS = oneshot_lut_runs(BITS);
         constexpr int ESTRIDE = 256;
@@ -155,10 +173,17 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     // ---- scale image of the wave: [tile t][unit u] x 8 groups (16 B) ----
 #pragma unroll
     for (int r = 0; r < NSL; ++r) {
-        vm_wait_regs<D + NX>(sv[r]);
+        vm_wait_regs<PRE * (1 + MT)>(sv[r]);
         *reinterpret_cast<uint4*>(smem + simg + (uint32_t)(((q + 4 * r) * 16 + u) * 16)) = make_uint4(sv[r].x, sv[r].y, sv[r].z, sv[r].w);
     }
+    FLUTE_KSTAMP(3);
     __syncthreads();                                               // table image visible to every wave
+    // the first half of the k-steps now, k-step i + AHEAD when k-step i is decoded: the two waves of a SIMD then
+    // alternate between requesting and decoding (all requests up front: the second wave of a SIMD only starts to request
+    // when the first is done - 25 K cycles per workgroup against 20 K: profiles/r03/skinny_stamps*.json)
+    static_for<AHEAD>([&](auto i_tag) { if constexpr (decltype(i_tag)::value >= PRE) issue_step(i_tag); });
+    __builtin_amdgcn_sched_barrier(0);
+    FLUTE_KSTAMP(4);
 
     const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
     f32x4_t acc[NI];
@@ -179,8 +204,10 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             constexpr int g = decltype(g_tag)::value;
             constexpr int I = g / NG, GI = g % NG;
             if constexpr (GI == 0) {
-                if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"((D - 1 - I) * 2) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"((D - 1 - I) * 3) : "memory");
+                if constexpr (I + AHEAD < D) issue_step(std::integral_constant<int, I + AHEAD>{});
+                constexpr int YOUNGER = ((I + AHEAD < D ? I + AHEAD : D - 1) - I) * (1 + MT);      // k-steps requested behind this one
+                if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"(YOUNGER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"(YOUNGER) : "memory");
                 const uint32_t sa = simg + (uint32_t)(u * 16) + (uint32_t)((((kp * D + I) * 32) >> lg) - g0e) * 2u;
 #pragma unroll
                 for (int t = 0; t < J; ++t) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(sc[I & 1][t]) : "v"(sa), "n"(t * 256) : "memory");
@@ -205,6 +232,10 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             if constexpr (GI == 0) {                               // the k-step's scale reads are older than its first group
 #pragma unroll
                 for (int t = 0; t < J; ++t) { uint32_t& r = sc[I & 1][t]; asm volatile("" : "+v"(r) : : "memory"); }
+                if constexpr (I == 0) { FLUTE_KSTAMP(5); }
+                if constexpr (I == 1) { FLUTE_KSTAMP(6); }
+                if constexpr (I == D / 2) { FLUTE_KSTAMP(7); }
+                if constexpr (I == D - 1) { FLUTE_KSTAMP(8); }
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -224,6 +255,7 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
+    FLUTE_KSTAMP(9);
     // ---- K reduction inside the workgroup: tile e is summed by wave e % KW, in wave order ----
     float4* red = reinterpret_cast<float4*>(smem + red_off);
 #pragma unroll
@@ -249,6 +281,17 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
         }
         store_tile(e, s);
     }
+#ifdef FLUTE_STAMPS
+    FLUTE_KSTAMP(10);
+    __builtin_amdgcn_s_waitcnt(0);
+    stamp[11] = __builtin_amdgcn_s_memtime();
+    stamp[12] = wall_clock64();
+    if (lane == 0 && stamps != nullptr) {
+        uint64_t* o = stamps + ((size_t)blockIdx.x * KW + wave) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef FLUTE_KSTAMP
 }
 
 }  // namespace flute_amd

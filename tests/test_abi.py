@@ -154,14 +154,19 @@ def test_plan_families_and_invariants():
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 19, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 17, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 4
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 18, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 8
-    # skinny MFMA kernel (family 5): 4-bit, 3 <= M <= 16, slabs of 64 columns filling 55..100 % of the CUs, K = 4096
+    # skinny MFMA kernel (family 5): 4-bit, 3 <= M <= 16, slabs of 64 columns filling 55..100 % of the CUs (or >= 1.7 rounds), K = 4096
     rc, p = plan(16, 11008, 4096)
     assert rc == 0 and p.family == 5 and (p.grid, p.waves, p.kw, p.ring_depth, p.splitk, p.workspace_needed) == (172, 8, 8, 16, 1, 0)
     assert p.lds_bytes <= 160 * 1024
     rc, p = plan(4, 14336, 4096)
     assert rc == 0 and p.family == 5 and p.grid == 224
-    for (M, N, K, bits, tid) in ((16, 4096, 4096, 4, 16), (16, 28672, 4096, 4, 16), (17, 14336, 4096, 4, 16), (2, 14336, 4096, 4, 16),
-                                 (16, 14336, 4096, 2, 0), (16, 14336, 8192, 4, 16), (16, 14336, 4096, 4, 17)):
+    rc, p = plan(16, 28672, 4096)                            # 448 slabs: 1.75 rounds
+    assert rc == 0 and p.family == 5 and p.grid == 448
+    rc, p = plan(16, 4096, 4096, tid=19)                     # QuantMapMode digit 3 at M <= 16: skinny wherever it exists
+    assert rc == 0 and p.family == 5 and p.grid == 64
+    for (M, N, K, bits, tid) in ((16, 4096, 4096, 4, 16), (16, 20480, 4096, 4, 16), (17, 14336, 4096, 4, 16), (2, 14336, 4096, 4, 16),
+                                 (16, 14336, 4096, 2, 0), (16, 14336, 8192, 4, 16), (16, 14336, 4096, 4, 17), (16, 14336, 4096, 4, 18),
+                                 (32, 14336, 4096, 4, 19)):
         rc, p = plan(M, N, K, bits=bits, tid=tid)
         assert rc == 0 and p.family != 5, (M, N, K, bits, tid)
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 8, 1024, 2048, 16, 256, 64 << 20, _lib.Overrides(family=5), q) == 0

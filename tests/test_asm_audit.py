@@ -54,3 +54,8 @@ def test_audit_rules_on_synthetic_streams(tmp_path):
     assert _audit_text(tmp_path, undef) == []
     live = load + "\tv_readfirstlane_b32 s10, v4\n\ts_add_i32 s11, s10, 64\n" + wait0
     assert len(_audit_text(tmp_path, live)) == 1
+    # packed fp32 with op_sel_hi:[0,..]: both halves of source 0 come from its LOW register - the high one is not read
+    bcast = load + "\tv_pk_mul_f32 v[36:37], v[3:4], v[36:37] op_sel_hi:[0,1]\n" + wait0
+    assert _audit_text(tmp_path, bcast) == []
+    assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[3:4], v[36:37]\n" + wait0)) == 1
+    assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[4:5], v[36:37] op_sel_hi:[0,1]\n" + wait0)) == 1

@@ -64,6 +64,36 @@ def _sgpr_mentions(text, n):
     return True, hits[0] and not any(hits[1:]) and not ops[0].startswith(("s_cmp", "s_cbranch", "s_bitcmp"))
 
 
+def _pk_f32_unread(text):
+    """VGPRs a packed-fp32 instruction names but does not read: `v_pk_mul_f32 d, v[a:a+1], v[b:b+1] op_sel_hi:[0,1]`
+    takes BOTH halves of source 0 from v[a] (op_sel picks the register of the low result, op_sel_hi of the high one;
+    defaults [0,..] / [1,..]) - hipcc uses this to broadcast a scalar held in the low register of a pair whose high
+    register belongs to something else."""
+    m = re.match(r"v_pk_(?:mul|add|fma)_f32\s+(.*)$", text)
+    if not m:
+        return set()
+    body = m.group(1)
+    mods = {"op_sel": None, "op_sel_hi": None}
+    for name in mods:
+        mm = re.search(name + r":\[([01,]+)\]", body)
+        if mm:
+            mods[name] = [int(x) for x in mm.group(1).split(",")]
+    ops = [o.strip() for o in re.sub(r"\s+op_sel(_hi)?:\[[01,]+\]", "", body).split(",")]
+    unread = set()
+    for i, o in enumerate(ops[1:]):                            # sources
+        mm = re.match(r"v\[(\d+):(\d+)\]$", o)
+        if not mm or int(mm.group(2)) != int(mm.group(1)) + 1:
+            continue
+        lo_sel = mods["op_sel"][i] if mods["op_sel"] and i < len(mods["op_sel"]) else 0
+        hi_sel = mods["op_sel_hi"][i] if mods["op_sel_hi"] and i < len(mods["op_sel_hi"]) else 1
+        picked = {lo_sel, hi_sel}
+        if 0 not in picked:
+            unread.add(int(mm.group(1)))
+        if 1 not in picked:
+            unread.add(int(mm.group(2)))
+    return unread
+
+
 def _dead_readfirstlane(lines, i, text):
     """hipcc materialises an UNDEF scalar with `v_readfirstlane_b32 sN, <any vgpr>`: the value is dead when sN is
     overwritten before it is read.  Follows the fall-through path only (a taken branch in between = not proven)."""
@@ -155,7 +185,7 @@ def audit(path):
             busy |= r
         for _, r in ds_set:
             busy |= r
-        hit = used & busy
+        hit = (used - _pk_f32_unread(text)) & busy
         if hit and not _dead_readfirstlane(all_lines, ln - 1, text):
             findings.append((kernel, ln, text, sorted(hit)))
     return findings
