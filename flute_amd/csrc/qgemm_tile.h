@@ -95,6 +95,9 @@ template <int LPS> __device__ __forceinline__ void dma_wait(int steps) {
 // chunk swizzles (an involution applied to the source address and to the read address): with
 // them the 16 lanes of every ds_read_b128 lane group hit 16 different 16-B bank slots
 __device__ __forceinline__ int swz_a(int row) { return (4 - (row >> 2)) & 3; }       // 16 rows x 4 chunks
+// activation pieces of 8 rows x 8 chunks (two pieces = the two row halves of a 16-row tile): the 16 lanes of a
+// ds_read_b128 lane group (rows 0..15, one chunk) then hit 16 different 16-B slots of the 256-B bank row
+__device__ __forceinline__ int swz_x(int row8, int h) { return (row8 >> 1) | (h << 2); }
 template <int R> __device__ __forceinline__ int swz_q(int row) {                      // 16/R rows x 4R chunks
     if constexpr (R == 1) return (4 - (row >> 2)) & 3;
     else if constexpr (R == 2) return (row >> 1) << 1;
@@ -197,12 +200,20 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
             qrow[w * NP + pl] = a.Q + (size_t)unit_row<BITS, TILEP>((slab + w) * SU + lrow, pl, a.N) * row_words;
-    const int arow = lane >> 2;
-    const int achunk = (lane & 3) ^ swz_a(arow);
-    const uint16_t* xrow[MT];
+    // Activations.  R = 1 (one k-step per macro-step): a piece is 16 rows x 64 B (lane L: row L / 4).  R > 1: a piece is
+    // 8 rows x 128 B - WHOLE cache lines (lane L: row L / 8, chunk L % 8 of the 64 k of k-steps 2 kh, 2 kh + 1): a request
+    // costs the CU's texture addresser time per line it touches (tools/stamps_skinny.py: ~270 cycles of a SIMD's memory
+    // issue for 16 half lines), and the activation requests are MT R of the MT R + NP SW requests of a macro-step.  Piece
+    // e = h (R / 2) + kh of a row tile: rows 8 h .. 8 h + 7.
+    constexpr bool XLINES = R > 1;
+    const int arow = XLINES ? (lane >> 3) : (lane >> 2);
+    const int achunk = XLINES ? (lane & 7) : ((lane & 3) ^ swz_a(arow));
+    const uint16_t* xrow[MT][XLINES ? 2 : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)      // row >= M: clamped; that accumulator column is never stored
-        xrow[mt] = A + (size_t)min(m0 + mt * 16 + arow, a.M - 1) * a.K;
+#pragma unroll
+        for (int h = 0; h < (XLINES ? 2 : 1); ++h)
+            xrow[mt][h] = A + (size_t)min(m0 + mt * 16 + h * 8 + arow, a.M - 1) * a.K;
     const int klim = a.K - 8;            // a lane never reads past its row (ragged last macro-step)
 
     // piece P of a macro-step starting at k0: P < QP weight piece (slab, plane), else activations (k-step s, row tile mt)
@@ -211,9 +222,15 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
             const int kq = min(k0 + qchunk * 8, klim);
             dma16(qrow[P] + (kq >> 1), slot_addr + P * 1024);
         } else {
-            const int s = (P - QP) / MT, mt = (P - QP) % MT;
-            const int ka = min(k0 + s * 32 + achunk * 8, klim);
-            dma16(xrow[mt] + ka, slot_addr + P * 1024);
+            const int e = (P - QP) / MT, mt = (P - QP) % MT;
+            if constexpr (XLINES) {
+                const int h = e / (R / 2), kh = e % (R / 2);
+                const int ka = min(k0 + kh * 64 + (achunk ^ swz_x(arow, h)) * 8, klim);
+                dma16(xrow[mt][h] + ka, slot_addr + P * 1024);
+            } else {
+                const int ka = min(k0 + e * 32 + achunk * 8, klim);
+                dma16(xrow[mt][0] + ka, slot_addr + P * 1024);
+            }
         }
     };
     auto issue = [&](int t, uint32_t slot_addr) {
@@ -270,7 +287,12 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     // ---- MFMA-side addresses inside a slot ----
     const uint32_t qread = (uint32_t)(ul * (4 * R)) * 16;            // + ((s*4 + q4) ^ swz) * 16
     const int qswz = swz_q<R>(ul);
-    const uint32_t aread = (uint32_t)(r16 * 4 + (q4 ^ swz_a(r16))) * 16;
+    const uint32_t aread = (uint32_t)(r16 * 4 + (q4 ^ swz_a(r16))) * 16;     // R = 1
+    uint32_t aread_s[R];                                                      // R > 1: k-step s of the macro-step
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+        aread_s[s] = (uint32_t)(((r16 >> 3) * (R / 2 > 0 ? R / 2 : 1) + (s >> 1)) * MT) * 1024u +
+                     (uint32_t)((r16 & 7) * 8 + ((((s & 1) * 4 + q4)) ^ swz_x(r16 & 7, r16 >> 3))) * 16u;
     const uint32_t lane_off = (uint32_t)(lane & ((1 << (TILE_LUT_SHIFT - 2)) - 1)) * 4;   // table copy of this lane
 
     // ---- pair table: entry e at [e * 128, +128): 32 copies of its 4 bytes ----
@@ -384,7 +406,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                     qw[s][0] = v.x; qw[s][1] = v.y; qw[s][2] = v.z; qw[s][3] = v.w;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const uint4 x = lds_ld128(slot + (QP + s * MT + mt) * 1024 + aread);
+                        const uint4 x = lds_ld128(slot + (QP + mt) * 1024 + aread_s[s]);
                         af[s][mt] = u32x4_t{x.x, x.y, x.z, x.w};
                     }
                 }
@@ -479,7 +501,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if ((dbg & 2) && mt > 0) { af[mt] = af[0]; continue; }
-                    const uint4 v = lds_ld128(slot + (QP + s * MT + mt) * 1024 + aread);
+                    const uint4 v = XLINES ? lds_ld128(slot + (QP + mt) * 1024 + aread_s[s]) : lds_ld128(slot + (QP + s * MT + mt) * 1024 + aread);
                     af[mt] = u32x4_t{v.x, v.y, v.z, v.w};
                 }
                 // Refill of this slot for macro-step t + D, spread over the k-step: a piece may be overwritten
@@ -487,7 +509,8 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                 // last k-step); one piece goes out after each column tile's MFMAs so that the wave is not
                 // parked in the texture addresser's queue for five pieces in a row
                 const bool refill = (t + D < nmacro) && !(dbg & 4);
-                const int NREF = MT + ((s == R - 1) ? QP : 0);       // constant after unrolling
+                // (whole-line activation pieces serve both k-steps of a pair: everything is refilled in the last k-step)
+                const int NREF = XLINES ? ((s == R - 1) ? LPS : 0) : MT + ((s == R - 1) ? QP : 0);       // constant after unrolling
                 if (refill) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // the pair lookups of (up to) four column tiles are issued before their first multiply:
                 // hipcc otherwise funnels them through one register (lookup, wait, multiply, 16 times)
@@ -534,7 +557,7 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                         if (refill) {
 #pragma unroll
                             for (int q = i; q < NREF; q += NMF)
-                                issue_piece(q < MT ? QP + s * MT + q : q - MT, kb + (t + D) * (32 * R), slot);
+                                issue_piece(XLINES ? q : (q < MT ? QP + s * MT + q : q - MT), kb + (t + D) * (32 * R), slot);
                         }
                     }
                 }
