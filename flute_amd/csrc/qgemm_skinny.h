@@ -27,7 +27,8 @@
 // cache lines costs ~60 cycles of the CU's addresser; asking for the same bytes line-coalesced (lane l: chunk l % 4 of row
 // l / 4) and moving them to the operand lanes with ds_bpermute was measured slower (16.7 us: the requests still cost
 // ~55 cycles - the cost is per line touched - and the k-steps grow from 520 to 850 cycles).
-// Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core.
+// Arithmetic: fp16 w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core; bf16 (no packed
+// multiply on gfx950) applies the group scale to the fp32 MFMA result of each group run, as qgemm_tile.h.
 // Host contract (api.hip: plan_skinny): 2- / 4-bit, K % (32 D) == 0, G even, group size >= 32 and D * 32 / g <= 8,
 // N % (16 J) == 0 (always: TileP >= 32), K / (32 D) <= KW.
 #pragma once
@@ -198,8 +199,12 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
         // outstanding" releases group g.
         static_assert(BITS == 4 && J == 4, "the skinny kernel is instantiated for 4-bit layers");
         constexpr int NG = 2;
+        constexpr bool PRE = __is_same(T, F16);                    // fp16: w^ = round_T(lut s) by v_pk_mul_f16 before the MFMA
         uint32_t v[2][8];
         uint32_t sc[2][J];
+        f32x4_t run[NI];
+#pragma unroll
+        for (int e = 0; e < NI; ++e) run[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         auto issue_group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             constexpr int I = g / NG, GI = g % NG;
@@ -208,9 +213,11 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
                 constexpr int YOUNGER = ((I + AHEAD < D ? I + AHEAD : D - 1) - I) * (1 + MT);      // k-steps requested behind this one
                 if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[I]), "+v"(xv[0][I]) : "n"(YOUNGER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[I]), "+v"(xv[0][I]), "+v"(xv[1][I]) : "n"(YOUNGER) : "memory");
+                if constexpr (PRE) {
                 const uint32_t sa = simg + (uint32_t)(u * 16) + (uint32_t)((((kp * D + I) * 32) >> lg) - g0e) * 2u;
 #pragma unroll
                 for (int t = 0; t < J; ++t) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(sc[I & 1][t]) : "v"(sa), "n"(t * 256) : "memory");
+                }
             }
             const uint32_t wd[4] = {w[I].x, w[I].y, w[I].z, w[I].w};
 #pragma unroll
@@ -224,14 +231,14 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             constexpr int g = decltype(g_tag)::value;
             constexpr int I = g / NG, GI = g % NG;
             if constexpr (g + 1 < NG * D) issue_group(std::integral_constant<int, g + 1>{});
-            constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? J : 0) : 0;
+            constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + ((PRE && (g + 1) % NG == 0) ? J : 0) : 0;
             uint32_t(&vv)[8] = v[g & 1];
             asm volatile("s_waitcnt lgkmcnt(%8)"
                          : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7])
                          : "n"(NEXT_READS) : "memory");
             if constexpr (GI == 0) {                               // the k-step's scale reads are older than its first group
 #pragma unroll
-                for (int t = 0; t < J; ++t) { uint32_t& r = sc[I & 1][t]; asm volatile("" : "+v"(r) : : "memory"); }
+                for (int t = 0; t < J; ++t) { uint32_t& r = sc[I & 1][t]; if constexpr (PRE) asm volatile("" : "+v"(r) : : "memory"); }
                 if constexpr (I == 0) { FLUTE_KSTAMP(5); }
                 if constexpr (I == 1) { FLUTE_KSTAMP(6); }
                 if constexpr (I == D / 2) { FLUTE_KSTAMP(7); }
@@ -242,11 +249,32 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
                 const int t = 2 * GI + tt;
                 u32x4_t a;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) a[ww] = NT::mul_scale(v[g & 1][ww * 2 + tt], sc[I & 1][t]);
+                for (int ww = 0; ww < 4; ++ww) a[ww] = PRE ? NT::mul_scale(v[g & 1][ww * 2 + tt], sc[I & 1][t]) : v[g & 1][ww * 2 + tt];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const u32x4_t b = {xv[mt][I].x, xv[mt][I].y, xv[mt][I].z, xv[mt][I].w};
-                    acc[t * MT + mt] = Mfma<T>::run(a, b, acc[t * MT + mt]);
+                    if constexpr (PRE) acc[t * MT + mt] = Mfma<T>::run(a, b, acc[t * MT + mt]);
+                    else run[t * MT + mt] = Mfma<T>::run(a, b, run[t * MT + mt]);
+                }
+            }
+            if constexpr (!PRE && GI == NG - 1) {
+                // bf16 (no packed multiply): the fp32 sums of a group run are scaled when the group (or the wave's range)
+                // ends; the accumulator's four rows are units 4 q .. 4 q + 3 of the slab
+                const int kabs = kp * D + I;
+                if ((((kabs + 1) * 32) & ((1 << lg) - 1)) == 0 || I == D - 1) {
+                    const uint32_t sa = simg + (uint32_t)(4 * q * 16) + (uint32_t)(((kabs * 32) >> lg) - g0e) * 2u;
+#pragma unroll
+                    for (int t = 0; t < J; ++t) {
+                        float sf[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sf[r] = NT::to_float((uint16_t)lds_ld16(sa + (uint32_t)(t * 256 + r * 16)));
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[t * MT + mt][r] = __builtin_fmaf(run[t * MT + mt][r], sf[r], acc[t * MT + mt][r]);
+                            run[t * MT + mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
                 }
             }
         });
