@@ -447,7 +447,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const long tiles256 = (long)ceil_div(M, 256) * (units / blk_units), tiles128 = (long)ceil_div(M, 128) * (units / blk_units);
         if (ov.family == kFamilyBlock) {
             blk_cfg = (ov.m_tiles == 4) ? 5 : 4;             // 128- / 256-row blocks of qgemm_block2.h
-            if (bits == 3) blk_cfg = 5;                      // 3-bit layers: 128-row blocks of qgemm_block3.h ...
+            if (bits == 3 && ov.m_tiles != 8) blk_cfg = 5;   // 3-bit layers: 128-row blocks of qgemm_block3.h unless 256 rows are asked for ...
             if (bits == 3 && (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4))
                 blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
         } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)48 << 20)) {
@@ -462,9 +462,11 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 const double last = rest == 0 ? 0.0 : (rest * 4 >= (long)num_sms * 3 ? busy : alone);
                 return ((double)whole * busy + last) * (double)K / 4096.0 + 3.0;
             };
-            // 3-bit layers (qgemm_block3.h): 128-row blocks only (78 / 85 us alone, 85 / 90 busy); the per-wave kernel
-            // runs them at 330-380 TFLOP/s
-            const double t256 = (bits == 3) ? 1e30 : block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
+            // 3-bit layers (qgemm_block3.h): 128-row blocks 78 / 85 us alone, 85 / 90 busy; 256-row blocks (round 3) 108 / 118
+            // alone, 124 / 128 busy (profiles/r03/block_lab_w3_256_row_blocks.jsonl); the per-wave kernel runs them at
+            // 330-380 TFLOP/s
+            const double t256 = (bits == 3) ? block_us(tiles256, bf ? 118.0 : 108.0, bf ? 128.0 : 124.0)
+                                            : block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
             const double t128 = (bits == 3) ? block_us(tiles128, bf ? 85.0 : 78.0, bf ? 90.0 : 85.0)
                                             : block_us(tiles128, bf ? 80.0 : 72.0, bf ? 89.0 : 81.0);
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
@@ -533,7 +535,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         p->grid = (unsigned)((long)tiles_m * tiles_n * splitk);
         p->block = 512;
         // pair table + three activation stages + per wave: two scale blocks and a sink
-        p->lds_bytes = (size_t)((128 << (2 * bits)) + 3 * (bm / 16) * 2 * 1024 + 8 * 3 * 1024);
+        // (3-bit 256-row blocks: + 18 KB, the second / third plane pieces of waves 6 and 7)
+        p->lds_bytes = (size_t)((128 << (2 * bits)) + 3 * (bm / 16) * 2 * 1024 + 8 * 3 * 1024 + ((bits == 3 && bm == 256) ? 18 * 1024 : 0));
         p->lut_copies = 32;
     } else {
         // M > decode range: MFMA kernel (qgemm_tile.h).  MT 16-row tiles per wave (1 for M <= 16),

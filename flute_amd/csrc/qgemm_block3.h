@@ -12,8 +12,11 @@
 // half step feeds both tiles, as for 4 bits - wave 6 takes (12,13) (two planes) and wave 7 takes (14,15): field 15
 // needs all three planes (5 VALU per lookup), one of which is field 14's.  Three instantiations of the body, chosen
 // by a wave-uniform branch; all execute the same barriers.
-// Everything else is qgemm_block2.h with RT = 8 (128-row blocks: wave 7's ring of three plane pieces per half step
-// leaves no registers for 16 row tiles, and every wave of a kernel gets the same allocation):
+// Everything else is qgemm_block2.h: RT = 8 (128-row blocks) or, round 3, RT = 16 (256-row blocks).  Wave 7's ring of
+// three plane pieces per half step x three stages is 72 registers - with 16 row tiles of accumulators (128) and every
+// wave of a kernel getting the same allocation, too many - so at RT = 16 the SECOND and THIRD plane pieces of waves 6
+// and 7 go to wave-private LDS by LDS-DMA (18 KB) and are read back, one half step ahead, with the fragments (246
+// registers, no scratch; 3-bit M = 4096 on 4096^2: 161.6 -> 127.1 us fp16, 172.5 -> 130.7 bf16):
 // stages, fragment slots, two barriers per step, requests riding between the MFMAs, exact step count.
 // Arithmetic: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation, one rounding of the output.
 // The per-wave MFMA kernel (qgemm_tile.h) ran these layers at 360-380 TFLOP/s (M = 4096).
@@ -30,11 +33,12 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     // 16 / 32 / 64 rows for small batches, launched with a grid-level K split (fp32 slabs + splitk_reduce_kernel): a
     // 3-bit wave of the per-wave kernel is 256 columns wide, so a 4096-wide layer gives it 16 column slabs; here the
     // same layer gives 16 column blocks x the K split, every weight looked up once.
-    static_assert(RT == 8 || RT == 4 || RT == 2 || RT == 1, "row tiles per block");
+    static_assert(RT == 16 || RT == 8 || RT == 4 || RT == 2 || RT == 1, "row tiles per block");
     constexpr int NW = 8, BM = RT * 16, NT2 = 2;
     constexpr int PIECES = RT * 2;                                 // 1-KB activation pieces per stage
     constexpr int PH = (PIECES + NW - 1) / NW;                     // ... requested by a wave (skinny blocks: one, some of them idle)
-    constexpr int LPR = 8 / RT;                                    // lookups issued after every row tile
+    constexpr int NS = RT < 8 ? RT : 8;                            // fragment slots (RT = 16: row tile R lives in slot R % 8, as qgemm_block2.h)
+    constexpr int LPR = RT >= 8 ? 1 : 8 / RT;                      // lookups issued after a row tile (RT = 16: after row tiles 8 .. 15)
     // stages = ring slots: batch t + NST - 1 is requested during step t.  (Six stages for the skinny blocks measured
     // SLOWER than three - 4096^2 M = 16: 18.5 vs 15.8 us: they are not latency-bound; what they pay is the fixed part,
     // prologue + fp32 slabs + the reduce launch, ~8 us of a 16-us call.)
@@ -97,6 +101,10 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const uint32_t wv_dp = 32u * row_bytes;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
+    // RT = 16 (256-row blocks): the SECOND and THIRD plane pieces of waves 6 / 7 go to wave-private LDS (LDS-DMA) instead of
+    // the register ring - 16 row tiles of accumulators leave no registers for three planes x three stages x two half steps
+    const uint32_t pl_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + NW * 3072u + (wave == 7 ? 6u * 1024u : 0u);   // wave-uniform (M0 of the DMA)
+    const uint32_t pl_lane = pl_base + (uint32_t)lane * 16u;
     const uint32_t x_lds0 = x_mine ? (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u : sc_sink;     // idle request: zeros into the sink
 
     {   // pair table: 64 entries, 32 copies each (128-B stride)
@@ -129,7 +137,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 15)) + ((lane >> 4) ? f1 : f0) * TILEP) * a.G) * 2) : 0x80000000u;
 
         static_assert((NST - 2) * BATCH <= 63, "vmcnt is six bits");
-        u32x4_t w[NST][2][NPL];
+        constexpr bool XLDS = RT == 16 && NPL > 1;                 // planes 1 .. NPL-1 through LDS
+        constexpr int NREG = XLDS ? 1 : NPL;                       // planes in the register ring
+        constexpr int NX = NPL - NREG;
+        u32x4_t w[NST][2][NREG];
+        u32x4_t pw[NX > 0 ? NX : 1];                               // the LDS planes of the NEXT half step
         auto issue_one = [&](auto slot_tag, auto i_tag, int ustep) {
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int i = decltype(i_tag)::value;
@@ -142,7 +154,10 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 uint32_t vo;
                 if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
                 else vo = (c == 0) ? wv0 : wv1;
-                w[slot][h][c] = buf_load16(vo, w_srd, k0 * 2u + (uint32_t)h * 64u);
+                if constexpr (XLDS && c >= 1)
+                    dma16_buf(vo, w_srd, k0 * 2u + (uint32_t)h * 64u, pl_base + (uint32_t)(((slot * 2 + h) * NX + (c - 1)) * 1024));
+                else
+                    w[slot][h][c] = buf_load16(vo, w_srd, k0 * 2u + (uint32_t)h * 64u);
             } else {
                 const int g = (int)(k0 >> a.lg);
                 const bool blk_start = (ustep < nsteps) && ((g & 7) == 0 || ustep == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
@@ -158,11 +173,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         auto wait_batch = [&](auto slot_tag, auto n_tag) {         // releases ring slot `slot` once <= n requests are outstanding
             constexpr int n = decltype(n_tag)::value;
             auto& ws = w[decltype(slot_tag)::value];               // (named first: clang does not capture through asm operands)
-            if constexpr (NPL == 3)
+            if constexpr (NREG == 3)
                 asm volatile("s_waitcnt vmcnt(%6)"
                              : "+v"(ws[0][0]), "+v"(ws[0][1]), "+v"(ws[0][2]), "+v"(ws[1][0]), "+v"(ws[1][1]), "+v"(ws[1][2])
                              : "n"(n) : "memory");
-            else if constexpr (NPL == 2)
+            else if constexpr (NREG == 2)
                 asm volatile("s_waitcnt vmcnt(%4)"
                              : "+v"(ws[0][0]), "+v"(ws[0][1]), "+v"(ws[1][0]), "+v"(ws[1][1])
                              : "n"(n) : "memory");
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         uint32_t v[8];                                             // hidden lookups of the NEXT half step: [tile][word]
-        u32x4_t af[RT];                                            // fragment slots = the row tiles
+        u32x4_t af[NS];                                            // fragment slots (row tile R in slot R % 8)
         uint32_t scn[NT2];
 
         auto scales = [&](int t, int h) {
@@ -191,34 +206,49 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
             asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");
         };
-        auto lookup = [&](const u32x4_t (&qw)[NPL], auto n_tag) {
+        // plane c of (slot, half): a ring register, or (XLDS, c >= 1) the register its LDS copy was read into
+        auto lookup = [&](auto slot_tag, auto h_tag, auto n_tag) {
             constexpr int n = decltype(n_tag)::value;              // tile n / 4, word n % 4
             constexpr int ww = n & 3;
+            const u32x4_t& q0 = w[decltype(slot_tag)::value][decltype(h_tag)::value][0];
+            const u32x4_t& q1 = XLDS ? pw[0] : w[decltype(slot_tag)::value][decltype(h_tag)::value][NREG > 1 ? 1 : 0];
+            const u32x4_t& q2 = XLDS ? pw[NX > 1 ? 1 : 0] : w[decltype(slot_tag)::value][decltype(h_tag)::value][NREG > 2 ? 2 : 0];
             uint32_t idx;
             if constexpr (LAST) {
-                if constexpr (n < 4) idx = __builtin_amdgcn_ubfe(qw[2][ww], 24u, 6u);              // field 14: plane 2, bit 24
-                else idx = (qw[0][ww] >> 30) | ((qw[1][ww] >> 28) & 0xcu) | ((qw[2][ww] >> 26) & 0x30u);   // field 15 (common.h field<3>)
+                if constexpr (n < 4) idx = __builtin_amdgcn_ubfe(q2[ww], 24u, 6u);                 // field 14: plane 2, bit 24
+                else idx = (q0[ww] >> 30) | ((q1[ww] >> 28) & 0xcu) | ((q2[ww] >> 26) & 0x30u);      // field 15 (common.h field<3>)
             } else if constexpr (n < 4) {
-                idx = __builtin_amdgcn_ubfe(qw[0][ww], sh0, 6u);
+                idx = __builtin_amdgcn_ubfe(q0[ww], sh0, 6u);
             } else {
-                idx = __builtin_amdgcn_ubfe(qw[KIND == 0 ? 0 : 1][ww], sh1, 6u);
+                idx = __builtin_amdgcn_ubfe((KIND == 0 ? q0 : q1)[ww], sh1, 6u);
             }
             v[n] = lds_lookup32((idx << 7) | lane_off);
+        };
+        auto planes = [&](auto slot_tag, auto h_tag) {            // hidden reads of the LDS planes of (slot, half)
+            if constexpr (XLDS) {
+                [&]<int... C>(std::integer_sequence<int, C...>) {
+                    (([&] {
+                        u32x4_t& dst = pw[C];
+                        const uint32_t addr = pl_lane;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr),
+                                     "n"(((decltype(slot_tag)::value * 2 + decltype(h_tag)::value) * NX + C) * 1024) : "memory");
+                    }()), ...);
+                }(std::make_integer_sequence<int, NX>{});
+            }
         };
         auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
             constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + R) * 1024;
-            static_assert(off < 65536, "one address register covers the three stages");
-            u32x4_t& dst = af[R];
-            const uint32_t addr = frag_lo;                         // (named first: clang does not capture through asm operands)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+            u32x4_t& dst = af[R & 7];
+            const uint32_t addr = off < 65536 ? frag_lo : frag_lo + 65536u;     // (named first: clang does not capture through asm operands)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
         };
         auto wait_lds = [&]() {
-            if constexpr (RT == 8)
+            if constexpr (RT >= 8)
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                               "+v"(af[0]), "+v"(af[1 % RT]), "+v"(af[2 % RT]), "+v"(af[3 % RT]), "+v"(af[4 % RT]), "+v"(af[5 % RT]),
-                               "+v"(af[6 % RT]), "+v"(af[7 % RT]), "+v"(scn[0]), "+v"(scn[1])
+                               "+v"(af[0]), "+v"(af[1 % NS]), "+v"(af[2 % NS]), "+v"(af[3 % NS]), "+v"(af[4 % NS]), "+v"(af[5 % NS]),
+                               "+v"(af[6 % NS]), "+v"(af[7 % NS]), "+v"(scn[0]), "+v"(scn[1])
                              : : "memory");
             else if constexpr (RT == 4)
                 asm volatile("s_waitcnt lgkmcnt(0)"
@@ -256,11 +286,22 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], scn[c]);
             scales(t + h, nh);
-            const u32x4_t (&qw)[NPL] = w[nslot][nh];
+            planes(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{});
             auto row = [&](auto r_tag) {
                 constexpr int R = decltype(r_tag)::value;
+                if constexpr (R >= 8) {
+                    // (RT = 16, as qgemm_block2.h) row tile R's fragment was requested after row tile R-8's MFMAs of THIS half
+                    // step; younger than it: the fragments of row tiles R+1..15 and (fragment, lookup) of row tiles 8..R-1.
+                    // The LDS planes were read before row tile 0: they have returned with it
+                    u32x4_t& slot_reg = af[R & 7];
+                    u32x4_t& p0 = pw[0];
+                    u32x4_t& p1 = pw[NX > 1 ? 1 : 0];                // (an operand list must not name one register twice)
+                    if constexpr (NX == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(slot_reg), "+v"(p0), "+v"(p1) : "n"(7 + (R - 8)) : "memory");
+                    else if constexpr (NX == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(slot_reg), "+v"(p0) : "n"(7 + (R - 8)) : "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(slot_reg) : "n"(7 + (R - 8)) : "memory");
+                }
 #pragma unroll
-                for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
+                for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R & 7], acc[R][c]);
                 if constexpr (h == 0)                              // batch t+NST-1: RPR requests after every row tile
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         (([&] {
@@ -269,10 +310,14 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                                           std::integral_constant<int, R * RPR + Q>{}, t + NST - 1);
                         }()), ...);
                     }(std::make_integer_sequence<int, RPR>{});
-                frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
-                [&]<int... L>(std::integer_sequence<int, L...>) {
-                    (lookup(qw, std::integral_constant<int, R * LPR + L>{}), ...);
-                }(std::make_integer_sequence<int, LPR>{});
+                if constexpr (RT == 16 && R < 8) {
+                    frag(slot_tag, h_tag, std::integral_constant<int, R + 8>{});
+                } else {
+                    frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, std::integral_constant<int, R & 7>{});
+                    [&]<int... L>(std::integer_sequence<int, L...>) {
+                        (lookup(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, std::integral_constant<int, (R & 7) * LPR + L>{}), ...);
+                    }(std::make_integer_sequence<int, LPR>{});
+                }
             };
             [&]<int... R>(std::integer_sequence<int, R...>) {
                 (row(std::integral_constant<int, R>{}), ...);
@@ -284,13 +329,19 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         scales(0, 0);
+        planes(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (XLDS) {
+            u32x4_t& p0 = pw[0];
+            u32x4_t& p1 = pw[NX > 1 ? 1 : 0];
+            if constexpr (NX == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(scn[0]), "+v"(scn[1]) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(scn[0]), "+v"(scn[1]) : : "memory");
+        }
         {
-            const u32x4_t (&qw)[NPL] = w[0][0];
             [&]<int... R>(std::integer_sequence<int, R...>) {
                 (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
-            }(std::make_integer_sequence<int, RT>{});
+            }(std::make_integer_sequence<int, NS>{});
             [&]<int... L>(std::integer_sequence<int, L...>) {
-                (lookup(qw, std::integral_constant<int, L>{}), ...);
+                (lookup(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, L>{}), ...);
             }(std::make_integer_sequence<int, 8>{});
         }
         auto step = [&](auto slot_tag, int t) {

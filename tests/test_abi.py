@@ -104,7 +104,9 @@ def test_plan_families_and_invariants():
     rc, p = plan(4096, 4096, 4096, bits=2, tid=0)
     assert rc == 0 and p.family == 3 and p.m_block == 4 and p.lds_bytes <= 160 * 1024      # 2-bit layers too
     rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
-    assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 512 and p.lds_bytes == 80 * 1024     # 3 bits: 128-row blocks
+    assert rc == 0 and p.family == 3 and p.m_block == 4 and p.grid == 256 and p.lds_bytes == 146 * 1024    # 3 bits: 256-row blocks too (planes 2, 3 of two waves in LDS)
+    rc, p = plan(1024, 4096, 4096, bits=3, tid=4)
+    assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 128 and p.lds_bytes == 80 * 1024     # fewer blocks: 128 rows
     rc, p = plan(300, 1024, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches

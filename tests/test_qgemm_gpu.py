@@ -423,7 +423,8 @@ def test_block_prefill_kernel(env):
             E = torch.zeros(M, K, dtype=dtype)
             E[torch.arange(M), ks] = 1
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
-            # 256- / 128-row blocks of the 1 x 8 wave split (qgemm_block2.h), with and without a grid K split
+            # 256- / 128-row blocks of the 1 x 8 wave split (qgemm_block2.h; 3 bits: qgemm_block3.h, whose 256-row blocks keep
+            # the second / third bit-plane pieces of two waves in LDS), with and without a grid K split
             for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4),
                         dict(family=3, m_tiles=8, splitk=2), dict(family=3, m_tiles=4, splitk=2)):
                 ovr = dev.Overrides(**shp)
@@ -464,7 +465,10 @@ def test_block_prefill_kernel(env):
     p = dev.get_plan(4096, 4096, 4096, 2, 64, 0, 256, torch.float16)
     assert p["family"] == 3 and p["m_block"] == 4, p                                 # 2-bit layers: the 1 x 8 split only
     p = dev.get_plan(4096, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)
-    assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 512, p          # 3 bits: 128-row blocks (qgemm_block3.h)
+    assert p["family"] == 3 and p["m_block"] == 4 and p["grid"] == 256, p          # 3 bits: 256-row blocks (qgemm_block3.h, round 3)
+    p = dev.get_plan(1024, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)
+    assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 128, p          # ... 128-row blocks where those fill more CUs
+    assert dev.get_plan(700, 1024, 2048, 3, 64, 4, 256, torch.float16, dev.Overrides(family=3, m_tiles=8))["m_block"] == 4
 
 
 # ---------------------------------------------------------------------------

@@ -130,8 +130,6 @@ def timing_b2(bits=2):
                       (1024, 4096, 4096), (512, 8192, 8192), (256, 28672, 8192)):
         for dtype in (f16, bf16):
             for shp in (dict(family=2), dict(family=3, m_tiles=8), dict(family=3, m_tiles=4), dict()):
-                if bits == 3 and shp.get("m_tiles") == 8:
-                    continue
                 lay = bench.Layer(M, N, K, bits, 64, dtype, d, bench.copies_for(N, K, bits))
                 lay.template_id = tid_of(bits, 32)
                 if shp.get("family") == 2:
