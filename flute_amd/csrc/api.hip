@@ -222,7 +222,8 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
 // Stages 2..5 -> rank 0..3.
 int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t, const Ovr& ov,
                  flute_plan* p, OneArgs* oa) {
-    if (M != 1 || lg < 6 || ((K >> lg) & 1) || K % 512) return FLUTE_ERR_SHAPE;
+    if (M < 1 || M > 2 || lg < 6 || ((K >> lg) & 1) || K % 512) return FLUTE_ERR_SHAPE;
+    int mb = 1; while (mb < M) mb <<= 1;                      // rows per pass (their staged activations must fit LDS: below)
     const int J = (bits == 3) ? 16 : 16 / bits;
     const int units = N / J;
     const int npieces = K / 512;
@@ -240,7 +241,7 @@ int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute
     for (int W = wcap; W >= 4; --W) {
         if (ov.waves > 0 && W != std::min(ov.waves, wcap)) continue;
         if (bits != 2 && ceil_div(runs, W) > 8) continue;
-        const size_t lds = persist_lds_bytes(bits, D, NS, lg, K, W);
+        const size_t lds = persist_lds_bytes(bits, mb, D, NS, lg, K, W);
         if (lds > (size_t)kMaxLds) continue;
         const int per_cu = std::max(1, std::min((int)((size_t)kMaxLds / lds), 16 / W));
         for (int c = 1; c <= per_cu; ++c) {
@@ -264,7 +265,7 @@ int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute
     if (ov.waves > 0 || ov.m_tiles > 0) pick = 0;
     const Shape& best = cands[pick];
     p->family = 0;
-    p->m_block = 1; p->waves = best.W; p->kw = 1; p->splitk = 1; p->k_per_split = K;
+    p->m_block = mb; p->waves = best.W; p->kw = 1; p->splitk = 1; p->k_per_split = K;
     p->grid = (unsigned)best.nwg; p->block = (unsigned)(best.W * 64);
     p->lds_bytes = best.lds; p->lut_copies = 32;
     p->ring_depth = D; p->visits = best.nvis; p->k_chunks = nch; p->one_shot = 3;
@@ -411,6 +412,14 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // 4096^2 M = 4: 9.9 against 13.7 us; larger 3-bit layers are faster on the MFMA kernel.)
     const int dec_max = 4;
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
+    const bool auto_digit = (bits == 4) ? (template_id % 4) == 0 : t.sms_multiple == 1;
+    auto persist_auto_ok = [&](int rows) {
+        if (ov.one_shot >= 0 || ov.depth > 0 || ov.splitk > 1 || !auto_digit) return false;
+        if ((size_t)N * K < ((size_t)40 << 20) || (long)units < 6L * num_sms) return false;
+        flute_plan tmp;
+        memset(&tmp, 0, sizeof(tmp));
+        return plan_persist(bits, lg, rows, N, K, num_sms, t, ov, &tmp, nullptr) == FLUTE_OK;
+    };
     int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
     // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), by template (4-bit QuantMapMode digit 3 at M <= 16, where
@@ -495,10 +504,11 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
         if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
         bool taken = false;
-        // persistent one-shot kernel: by override, or automatically for one row on layers of >= 40 M weights that give
+        // persistent one-shot kernel: by override, or automatically (one or two rows; four rows measured 1.7x the one-row
+        // time - no faster than the MFMA kernel, profiles/r03/decode_lab_persist_rows.jsonl) on layers of >= 40 M weights that give
         // every CU six whole unit rows (below that the in-workgroup K split of the other two kernels wins:
         // profiles/r03/persist_lab.txt)
-        const bool persist_auto = want < 0 && M == 1 && (size_t)N * K >= ((size_t)40 << 20) && (long)units >= 6L * num_sms;
+        const bool persist_auto = want < 0 && persist_auto_ok(M);
         if (want == 2 || persist_auto) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
@@ -843,14 +853,14 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
 
     if (p.family == 0 && p.one_shot == 3) {
         const int had = had_log > 0 ? 1 : 0;
-        PersistKernel fn = num_bits == 4 ? persist_kernel_b4(dtype, t.tile_p, oa.depth, oa.nsets, had)
-                           : (num_bits == 2 ? persist_kernel_b2(dtype, t.tile_p, oa.depth, oa.nsets, had)
-                                            : persist_kernel_b3(dtype, t.tile_p, oa.depth, oa.nsets, had));
+        PersistKernel fn = num_bits == 4 ? persist_kernel_b4(dtype, t.tile_p, p.m_block, oa.depth, oa.nsets, had)
+                           : (num_bits == 2 ? persist_kernel_b2(dtype, t.tile_p, p.m_block, oa.depth, oa.nsets, had)
+                                            : persist_kernel_b3(dtype, t.tile_p, p.m_block, oa.depth, oa.nsets, had));
         if (!fn) return FLUTE_ERR_SHAPE;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
         const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
-        uint32_t geo = PersistGeo::pack(oa.lg, p.waves, oa.nch, oa.ipw, had_log, oneshot_x_in_holes(num_bits, 1, K) ? 1 : 0);
+        uint32_t geo = PersistGeo::pack(oa.lg, p.waves, oa.nch, oa.ipw, had_log, oneshot_x_in_holes(num_bits, p.m_block, K) ? 1 : 0, M);
         float hs = had_scale;
         int nvis = oa.nvis, nwg = oa.nwg;
         void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &nvis, &D, &hs, &nwg};

@@ -20,11 +20,11 @@ OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pip
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had, int pipe);
-// persistent one-shot decode kernel (qgemm_persist.h): one row, depth = pieces per segment, nsets = register sets
+// persistent one-shot decode kernel (qgemm_persist.h): mb rows per pass (1/2), depth = pieces per segment, nsets = register sets
 typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
-PersistKernel persist_kernel_b4(int dtype, int tile_p, int depth, int nsets, int had);
-PersistKernel persist_kernel_b2(int dtype, int tile_p, int depth, int nsets, int had);
-PersistKernel persist_kernel_b3(int dtype, int tile_p, int depth, int nsets, int had);
+PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int nsets, int had);
+PersistKernel persist_kernel_b2(int dtype, int tile_p, int mb, int depth, int nsets, int had);
+PersistKernel persist_kernel_b3(int dtype, int tile_p, int mb, int depth, int nsets, int had);
 // skinny MFMA kernel (qgemm_skinny.h): 4-bit, M <= 16, depth = k-steps per wave (4/8/16)
 typedef void (*SkinnyKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, uint64_t*);
 SkinnyKernel skinny_kernel_b4(int dtype, int tile_p, int depth);

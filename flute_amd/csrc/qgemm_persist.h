@@ -8,7 +8,8 @@
 // Same arithmetic, table / lookup scheme and wire format as qgemm_oneshot.h; decode loop = pipelined_pieces().
 // Replaces, like the ring kernel (qgemm_stream.h), the reference's Stream-K main loop for M = 1
 // (flute/csrc/qgemm_kernel.hpp:617-712, tile_scheduler_utils.hpp:460-481).
-// Host contract (api.hip: plan_persist): M = 1, K a whole number of chunks of D pieces (K % (512 D) == 0), G even,
+// Host contract (api.hip: plan_persist): M <= MB in {1, 2} rows whose staged activations fit LDS beside
+// the table image, K a whole number of chunks of D pieces (K % (512 D) == 0), G even,
 // group size >= 64, at most 8 waves (two register sets of D pieces: the 256-register budget of two waves per SIMD).
 #pragma once
 #include "qgemm_oneshot.h"
@@ -16,18 +17,18 @@
 namespace flute_amd {
 
 struct PersistGeo {     // packed launch geometry (one kernel-argument dword, preloaded)
-    static constexpr uint32_t pack(int lg, int waves, int nch, int ipw, int had_log, int xh) {
+    static constexpr uint32_t pack(int lg, int waves, int nch, int ipw, int had_log, int xh, int M) {
         return (uint32_t)lg | ((uint32_t)waves << 4) | ((uint32_t)nch << 9) | ((uint32_t)ipw << 17) |
-               ((uint32_t)had_log << 24) | ((uint32_t)xh << 28);
+               ((uint32_t)had_log << 24) | ((uint32_t)xh << 28) | ((uint32_t)(M - 1) << 29);
     }
 };
-__host__ __device__ constexpr size_t persist_lds_bytes(int bits, int depth, int nsets, int lg, int K, int waves) {
+__host__ __device__ constexpr size_t persist_lds_bytes(int bits, int mb, int depth, int nsets, int lg, int K, int waves) {
     const int J = (bits == 3) ? 16 : 16 / bits;
-    return (size_t)oneshot_lut_bytes(bits) + (oneshot_x_in_holes(bits, 1, K) ? 0 : (size_t)((K + 511) / 512 * 512) * 2) +
+    return (size_t)oneshot_lut_bytes(bits) + (oneshot_x_in_holes(bits, mb, K) ? 0 : (size_t)mb * ((K + 511) / 512 * 512) * 2) +
            (size_t)waves * nsets * J * depth * (512 >> lg) * 2;
 }
 
-template <typename T, int BITS, int TILEP, int D, int NS, bool HAD>
+template <typename T, int BITS, int TILEP, int MB, int D, int NS, bool HAD>
 __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int nvis, void* __restrict__ Dp, float had_scale,
@@ -40,10 +41,11 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     constexpr int NSL = oneshot_scale_loads(BITS, D);
     constexpr int LUT = oneshot_lut_bytes(BITS);
     constexpr int ESTRIDE = (BITS == 3) ? 128 : 256;
-    constexpr int XPR = 4;
+    constexpr int XPR = 4 / MB;                                    // activation pieces a thread stages from registers, per row
+    constexpr int NXV = MB * XPR;
     constexpr int SEG = NSL + D * NP;                              // hidden loads of one segment
     constexpr int AHEAD = (NS - 1) * SEG;                          // loads of the segments requested ahead
-    static_assert((D - 1) * NP + NSL + AHEAD <= 63 && XPR + AHEAD <= 63, "vmcnt is a 6-bit counter");
+    static_assert((D - 1) * NP + NSL + AHEAD <= 63 && NXV + AHEAD <= 63, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     const int lg = geo & 15, W = (geo >> 4) & 31, nch = (geo >> 9) & 255;
     const int ipw = (geo >> 17) & 127, had_log = (geo >> 24) & 15;
     const bool xh = (geo >> 28) & 1;
+    const int M = (int)((geo >> 29) & 3) + 1;                      // rows (<= MB)
     const int nthr = W * 64;
     const int units = N >> LJ;
     const int G = K >> lg;
@@ -63,9 +66,11 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     const int gpp = 512 >> lg;
     const int ngm = D * gpp;
     const uint32_t x_off = LUT;
-    const uint32_t s_off = x_off + (xh ? 0u : (uint32_t)(KX * 2));
-    auto x_addr = [&](int pidx) -> uint32_t {
-        return xh ? (uint32_t)((pidx >> 3) * 256 + 128 + (pidx & 7) * 16) : x_off + (uint32_t)(pidx * 16);
+    const uint32_t s_off = x_off + (xh ? 0u : (uint32_t)(MB * KX * 2));
+    // byte address of the 16-B piece `pidx` (8 k each) of staged row m (as qgemm_oneshot.h)
+    auto x_addr = [&](int m, int pidx) -> uint32_t {
+        return xh ? (uint32_t)((m * (KX >> 6) + (pidx >> 3)) * 256 + 128 + (pidx & 7) * 16)
+                  : x_off + (uint32_t)(m * KX * 2 + pidx * 16);
     };
     const uint32_t s_wave_bytes = (uint32_t)(J * ngm * 2);
     const uint32_t sbase = s_off + (uint32_t)(wave * NS) * s_wave_bytes;   // one image per register set
@@ -76,14 +81,16 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     uint32_t lut_v;
     if constexpr (BITS == 2) lut_v = buf_load4((uint32_t)(lane & 15) * 4u, lut_srd);
     else lut_v = buf_load4((uint32_t)(run0 * 8 + lane) * 4u, lut_srd);
-    const srd_t x_srd = make_srd(Ap, (uint32_t)min((size_t)K * 2, (size_t)0xfffffff0u));
+    const srd_t x_srd = make_srd(Ap, (uint32_t)min((size_t)M * K * 2, (size_t)0xfffffff0u));
     const int xrow_pieces = KX >> 3;
-    ring16_t xv[XPR];
+    ring16_t xv[MB][XPR];
 #pragma unroll
-    for (int r = 0; r < XPR; ++r) {
-        const int pidx = r * nthr + tid;
-        xv[r] = buf_load16(pidx < xrow_pieces ? (uint32_t)pidx * 16u : 0x80000000u, x_srd, 0);
-    }
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) {
+            const int pidx = r * nthr + tid;
+            xv[m][r] = buf_load16(pidx < xrow_pieces ? (uint32_t)(((size_t)min(m, M - 1) * K + (size_t)pidx * 8) * 2) : 0x80000000u, x_srd, 0);
+        }
 
     // ---- segments: (visit v, chunk c) = pieces c D .. c D + D - 1 of unit (blockIdx + v nwg) W + wave ----
     const srd_t s_srd = make_srd(Sp, (uint32_t)min((size_t)N * G * 2, (size_t)0xfffffff0u));
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- table image (as qgemm_oneshot.h) ----
-    vm_wait_regs<XPR + AHEAD>(lut_v);
+    vm_wait_regs<NXV + AHEAD>(lut_v);
     {
         constexpr int RUNS = oneshot_lut_runs(BITS);
         const int nrun = max(0, min(ipw, RUNS - run0));
@@ -153,25 +160,28 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
             }
         }
     }
-    // ---- activations -> LDS (fused pre-rotation: a wave's 64 pieces are 512 consecutive k) ----
+    // ---- activations -> LDS (fused pre-rotation: a wave's 64 pieces are 512 consecutive k of one row) ----
 #pragma unroll
-    for (int r = 0; r < XPR; ++r) vm_wait_regs<AHEAD>(xv[r]);
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-    for (int r = 0; r < XPR; ++r) {
-        const int pidx = r * nthr + tid;
-        if (pidx < xrow_pieces) {
-            uint32_t w[4] = {xv[r].x, xv[r].y, xv[r].z, xv[r].w};
-            if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
-            *reinterpret_cast<uint4*>(smem + x_addr(pidx)) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int r = 0; r < XPR; ++r) vm_wait_regs<AHEAD>(xv[m][r]);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < XPR; ++r) {
+            const int pidx = r * nthr + tid;
+            if (pidx < xrow_pieces) {
+                uint32_t w[4] = {xv[m][r].x, xv[m][r].y, xv[m][r].z, xv[m][r].w};
+                if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
+                *reinterpret_cast<uint4*>(smem + x_addr(m, pidx)) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
-    }
-    {                                                              // rows longer than XPR x threads pieces
-        const uint16_t* A = reinterpret_cast<const uint16_t*>(Ap);
+        const uint16_t* A = reinterpret_cast<const uint16_t*>(Ap);   // rows longer than XPR x threads pieces
         for (int pidx = XPR * nthr + tid; pidx < xrow_pieces; pidx += nthr) {
-            const uint4 t = *reinterpret_cast<const uint4*>(A + (size_t)pidx * 8);
+            const uint4 t = *reinterpret_cast<const uint4*>(A + (size_t)min(m, M - 1) * K + (size_t)pidx * 8);
             uint32_t w[4] = {t.x, t.y, t.z, t.w};
             if constexpr (HAD) fwht_piece<T>(w, lane, had_log, had_scale);
-            *reinterpret_cast<uint4*>(smem + x_addr(pidx)) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(smem + x_addr(m, pidx)) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
     __syncthreads();                                               // the only barrier: table image and activations are in LDS
@@ -179,10 +189,11 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     const uint32_t lane_off = (BITS == 2) ? (uint32_t)(lane & 31) * 8u : (uint32_t)(lane & 31) * 4u;
     const int gl = (8 * lane) >> lg;
     const uint32_t x_pshift = xh ? 11u : 10u;
-    const uint32_t x_lane0 = x_addr(lane);
+    const uint32_t x_lane0 = x_addr(0, lane);
+    const uint32_t x_row = xh ? (uint32_t)(KX >> 6) * 256u : (uint32_t)KX * 2u;
     const uint32_t s_piece = (uint32_t)(gpp * J) * 2u;
 
-    float acc[J][1];
+    float acc[J][MB];
     uint16_t* Dout = reinterpret_cast<uint16_t*>(Dp);
     // one segment from register set `set`: its scale image, its D pieces, and - on a unit's last chunk - the outputs
     auto do_seg = [&](auto set_tag, int v, int c) {
@@ -203,19 +214,27 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
         }
         if (c == 0) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) acc[j][0] = 0.f;
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
         }
-        pipelined_pieces<T, BITS, 1, D, AHEAD>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, 0u,
+        pipelined_pieces<T, BITS, MB, D, AHEAD>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, x_row,
                                              simg + (uint32_t)(gl * J) * 2u, s_piece, lane_off, acc);
         if (c == nch - 1) {
-            float tot[J];
+            float tot[J][MB];
 #pragma unroll
-            for (int j = 0; j < J; ++j) tot[j] = wave_sum64(acc[j][0]);
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) tot[j][m] = wave_sum64(acc[j][m]);
             const int unit = unit_of(v);
             if (lane == 0 && v < nvis && unit < units) {
                 const int col0 = unit_col0<BITS, TILEP>(unit);
 #pragma unroll
-                for (int j = 0; j < J; ++j) Dout[col0 + j * TILEP] = NT::from_float(tot[j]);
+                for (int m = 0; m < MB; ++m)
+                    if (m < M) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) Dout[(size_t)m * N + col0 + j * TILEP] = NT::from_float(tot[j][m]);
+                    }
             }
         }
     };

@@ -110,8 +110,12 @@ def test_plan_families_and_invariants():
     rc, p = plan(300, 1024, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches
-    rc, p = plan(2, 28672, 8192)
+    rc, p = plan(2, 28672, 8192, tid=19)                     # QuantMapMode digit 3: the ring kernel
     assert rc == 0 and p.family == 0 and p.waves == 14 and p.kw == 1 and p.visits == 2 and p.one_shot == 0
+    rc, p = plan(2, 28672, 8192)                             # two rows of a big layer: the persistent one-shot kernel as well
+    assert rc == 0 and p.family == 0 and p.one_shot == 3 and p.m_block == 2 and (p.waves, p.grid, p.visits) == (7, 256, 4)
+    rc, p = plan(2, 8192, 28672)                             # ... unless the two rows' activations do not fit LDS beside the table
+    assert rc == 0 and p.family == 0 and p.one_shot == 0
     # one row on layers of >= 64 M weights: the persistent one-shot kernel (qgemm_persist.h), ~8 waves per CU, every
     # unit slot used: 7168 unit rows = 256 workgroups x 7 waves x 4 visits, K = 4 segments of 4 pieces
     rc, p = plan(1, 28672, 8192)
@@ -146,10 +150,11 @@ def test_plan_families_and_invariants():
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=0), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(ring_depth=4), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 32, 1, 4096, 4096, 16, 256, 64 << 20, None, q) == 0 and q.one_shot == 0
-    # persistent one-shot kernel by override; not for two rows / ragged K / odd group counts (ring kernel instead)
+    # persistent one-shot kernel by override; not for three rows / ragged K / odd group counts (ring kernel instead)
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 3
     assert q.grid * q.waves * q.visits >= 1024 and q.k_chunks * q.ring_depth == 8
-    assert lib.flute_qgemm_plan_ex(0, 4, 64, 2, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 2, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 3 and q.m_block == 2
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 3, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(family=0, one_shot=2), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4352, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4416, 16, 256, 64 << 20, _lib.Overrides(one_shot=2), q) == 0 and q.one_shot == 0
     # template knobs: QuantMapMode digit 3 -> ring kernel, 1 / 2 -> one-shot with 4 / 8 pieces per wave
@@ -177,7 +182,7 @@ def test_plan_families_and_invariants():
     assert q.family == 5 and (q.waves, q.ring_depth) == (4, 16)
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 8, 1024, 4096 + 64, 16, 256, 64 << 20, _lib.Overrides(family=5), q) == 0 and q.family == 2
     # decode kernel: persistent grid never exceeds the unit groups
-    rc, p = plan(2, 28672, 8192)
+    rc, p = plan(2, 28672, 8192, tid=19)
     assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4
 
 

@@ -228,7 +228,7 @@ def test_decode_plan_shapes(env):
 
 def test_persistent_oneshot_kernel(env):
     """The persistent one-shot kernel (qgemm_persist.h; override one_shot = 2, automatic for one row on layers of
-    >= 64 M weights): 2/3/4 bits, both dtypes and TileP, every group size it takes, 2- and 4-piece segments, one and
+    >= 40 M weights): one and two rows, 2/3/4 bits, both dtypes and TileP, every group size it takes, 2- and 4-piece segments, one and
     several visits per wave (num_sms = 4), idle waves in the last workgroup, rows longer than the register-staged
     activations (K = 28672), the fused Hadamard rotation - against the oracle, one-hot rows bit-exact."""
     from flute_amd import dev
@@ -246,32 +246,36 @@ def test_persistent_oneshot_kernel(env):
         What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
         tid = template_ids_for(env.fa, bits, tile_p)[0]
         Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
-        X = (torch.randn(1, K) / 100).to(dtype)
-        ks = torch.randint(0, K, (1,))
-        E = torch.zeros(1, K, dtype=dtype)
-        E[0, ks] = 1
-        ref = X.float() @ What
-        ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
-        for shp in (dict(), dict(waves=8), dict(waves=5), dict(waves=4, ring_depth=2), dict(waves=6)):
-            for num_sms in (env.num_sms, 4):
-                ovr = dev.Overrides(family=0, one_shot=2, **shp)
-                plan = dev.get_plan(1, N, K, bits, g, tid, num_sms, dtype, ovr)
-                assert plan["family"] == 0 and plan["one_shot"] == 3, plan
-                assert plan["k_chunks"] * plan["ring_depth"] * 512 == K and plan["grid"] * plan["waves"] * plan["visits"] >= N // (16 if bits == 3 else 16 // bits)
-                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr)
-                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, shp, num_sms)
-                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr).cpu()
-                assert torch.equal(out1, ref1), (bits, tile_p, g, dtype, K, N, shp, num_sms)
+        for M in (1, 2):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            ref = X.float() @ What
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            for shp in (dict(), dict(waves=8), dict(waves=5), dict(waves=4, ring_depth=2), dict(waves=6)):
+                for num_sms in (env.num_sms, 4):
+                    ovr = dev.Overrides(family=0, one_shot=2, **shp)
+                    plan = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
+                    if plan["one_shot"] != 3:                    # the rows' activations do not fit LDS beside the table: ring kernel
+                        assert M > 1 and plan["family"] == 0, plan
+                        continue
+                    assert plan["m_block"] >= M and plan["k_chunks"] * plan["ring_depth"] * 512 == K
+                    assert plan["grid"] * plan["waves"] * plan["visits"] >= N // (16 if bits == 3 else 16 // bits)
+                    out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr)
+                    assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, shp, num_sms)
+                    out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, num_sms, ovr).cpu()
+                    assert torch.equal(out1, ref1), (bits, tile_p, g, dtype, K, N, M, shp, num_sms)
         for h in (512, 64):                              # fused rotation == rotate, then multiply
             if K % h:
                 continue
-            Xh = (torch.randn(1, K) / 10).to(dtype).to(d)
+            Xh = (torch.randn(2, K) / 10).to(dtype).to(d)
             fused = dev.qgemm_planned(Xh, Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=0, one_shot=2), hadamard_size=h)
             two = dev.qgemm_planned(env.fa.hadamard_transform(Xh, h), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms,
                                     dev.Overrides(family=0, one_shot=2))
             assert torch.equal(fused, two), (bits, dtype, K, h)
-    # what it does not take: more than one row, odd group counts, K that is not whole pieces -> the ring kernel
-    for (M, K) in ((2, 4096), (1, 4416), (1, 4096 + 256)):
+    # what it does not take: more than two rows, odd group counts, K that is not whole pieces -> the ring kernel
+    for (M, K) in ((3, 4096), (1, 4416), (1, 4096 + 256)):
         plan = dev.get_plan(M, 1024, K, 4, 64, template_ids_for(env.fa, 4, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=0, one_shot=2))
         assert plan["one_shot"] == 0, (M, K, plan)
     # automatic for one row on the big layers

@@ -213,6 +213,14 @@ if "time_persist_shape" in what:
             for c in (1, 2, 3, 4):
                 if w * c <= 16:
                     time_case(M, N, K, bits, 64, dt, dict(one_shot=2, waves=w, m_tiles=c), steps=200, tag=tag)
+if "time_persist_rows" in what:
+    for (tag, N, K, bits, dt) in (("28672x8192", 28672, 8192, 4, f16), ("8192x28672", 8192, 28672, 4, f16), ("14336x4096", 14336, 4096, 4, f16),
+                                  ("8192^2", 8192, 8192, 4, f16), ("28672x8192 W3", 28672, 8192, 3, bf16), ("28672x8192 W2", 28672, 8192, 2, f16)):
+        for M in (1, 2, 3, 4):
+            if bits == 3 and M > 2:
+                continue
+            for shp in (dict(), dict(family=0, one_shot=0), dict(family=0, one_shot=2), dict(family=2), dict(family=5)):
+                time_case(M, N, K, bits, 64, dt, shp, steps=200, tag=f"{tag} M={M}")
 if "time_persist" in what:
     timing_persist()
 os.makedirs("gpurun_out", exist_ok=True)
