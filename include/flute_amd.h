@@ -103,7 +103,7 @@ typedef struct flute_plan {
  *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
  *   ring_depth      decode: pieces in flight per wave (ring kernel 2/4; one-shot kernel 4/8, 3-bit 2/4); without
  *                   one_shot = 1 a given depth selects the ring kernel
- *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 2 persistent one-shot kernel (M = 1) */
+ *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 2 persistent one-shot kernel (M <= 2) */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;
