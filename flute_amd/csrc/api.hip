@@ -497,7 +497,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // front) and the persistent ring kernel (qgemm_stream.h).  Forced by override (one_shot 1 / 0; an explicit
         // ring depth or grid K split means the ring kernel) or by the template (4-bit QuantMapMode digit 1, 2:
         // one-shot with 4 / 8 pieces per wave, 3: ring; 2- / 3-bit SMs_Multiple 4: one-shot, 2: ring); automatic:
-        // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup; one row on larger layers:
+        // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup; one or two rows on larger layers:
         // the persistent one-shot kernel (qgemm_persist.h; override one_shot = 2).
         int want = ov.one_shot;
         if (want < 0 && (ov.depth > 0 || ov.splitk > 1)) want = 0;

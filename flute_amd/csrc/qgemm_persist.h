@@ -6,7 +6,7 @@
 // inside the workgroup): after the set-up barrier the waves never synchronise again - no arrival counters, no
 // cross-wave reduction - and a unit's outputs are stored by the wave that decoded it.
 // Same arithmetic, table / lookup scheme and wire format as qgemm_oneshot.h; decode loop = pipelined_pieces().
-// Replaces, like the ring kernel (qgemm_stream.h), the reference's Stream-K main loop for M = 1
+// Replaces, like the ring kernel (qgemm_stream.h), the reference's Stream-K main loop for M <= 2
 // (flute/csrc/qgemm_kernel.hpp:617-712, tile_scheduler_utils.hpp:460-481).
 // Host contract (api.hip: plan_persist): M <= MB in {1, 2} rows whose staged activations fit LDS beside
 // the table image, K a whole number of chunks of D pieces (K % (512 D) == 0), G even,
