@@ -424,15 +424,15 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
     // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), by template (4-bit QuantMapMode digit 3 at M <= 16, where
     // the digit's other meaning - two slabs per wave - does not exist; digit 2: never), or automatically (digit 0) for
-    // 3 <= M <= 16 on layers whose slabs (64 columns) fill 55 .. 100 % of the CUs in ONE round, or at least 1.7 rounds - a
-    // workgroup pulls its slab's weights AND all of X through one CU, so fewer slabs leave CUs idle and a few more than
-    // one round wait for a second.  Measured (profiles/r03/skinny_lab.jsonl, M = 16, us, per-wave kernel -> skinny):
+    // 3 <= M <= 16 on layers whose slabs (64 columns) fill 55 .. 100 % of the CUs in ONE round - a workgroup pulls its slab's
+    // weights AND all of X through one CU, so fewer slabs leave CUs idle; wider layers take the per-wave kernel with two
+    // slabs per wave (4096 x 28672: 21.1 us against 23.3 here).  Measured (profiles/r03/skinny_lab.jsonl, M = 16, us, per-wave kernel -> skinny):
     // 4096 x 11008 17.9 -> 12.0, 4096 x 14336 18.3 -> 12.6 (M = 4: 17.6 -> 11.8), 4096 x 28672 26.6 -> 23.3, 4096 x 6144
     // 13.1 -> 11.7, 2048 x 8192 7.6 -> 7.0; 4096 x 8192 10.0 -> 11.8 and 4096^2 7.6 -> 11.6 (not taken).
     {
         const int q4 = (bits == 4) ? template_id % 4 : -1;
         const long slabs5 = units / 16;
-        const bool fill5 = (slabs5 * 20 >= 11L * num_sms && slabs5 <= num_sms) || slabs5 * 10 >= 17L * num_sms;
+        const bool fill5 = slabs5 * 20 >= 11L * num_sms && slabs5 <= num_sms;
         const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 &&
                            ((q4 == 0 && K >= 4096 && fill5) || q4 == 3);
         if (ov.family == kFamilySkinny || auto5) {
@@ -571,19 +571,27 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const int mtiles = ceil_div(M, mt * 16);
         int R = 1;
         while (!combo_ok(R, mt)) R *= 2;
-        while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles < (long)num_sms * t.sms_multiple) R *= 2;
+        // One row tile (M <= 16): every workgroup pulls ALL of X through its CU, so lane sharing (R-fold more, narrower slabs)
+        // multiplies the activation traffic; it pays only while the slabs leave more than ~45 % of the CUs idle
+        // (profiles/r03/tile_lab_sw2_m16.jsonl: 10240 x 8192 M = 16, 160 slabs: R = 1 22.2 us, R = 2 26.8; 8192^2, 128 slabs:
+        // R = 2 14.7, R = 1 17.7).  Larger M: a slab per CU, as before.
+        const long fill_num = (mt == 1 && M <= 16) ? 11 : 20;      // slabs x row tiles x 20 >= fill_num x CUs: enough
+        while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles * 20 < fill_num * num_sms * t.sms_multiple) R *= 2;
         // QuantMapMode digit 1 (4-bit ids): no lane sharing above M = 16 - the chip is filled by the grid K split
         // instead (8192^2 M = 64: R = 1, MT = 4, split 2 26.2 us against R = 2, MT = 2 30.3; 4096^2 prefers R = 2:
         // the tuner decides)
-        if (bits == 4 && (template_id % 4) == 1 && M > 16 && combo_ok(1, mt)) R = 1;
+        if (bits == 4 && (template_id % 4) == 1 && combo_ok(1, mt)) R = 1;       // (M <= 16: with two slabs per wave, below)
         if (ov.m_block > 0 && combo_ok(ov.m_block, mt)) R = ov.m_block;
         // SW = 2 slabs per wave (4-bit, no lane sharing, fp16 up to MT = 4 / bf16 up to MT = 2: the bf16 path
         // keeps a second accumulator set): every activation fragment then serves 8 column tiles and the
         // texture-path traffic per MFMA drops by 40 %.  Worth it once halving the slab count still leaves a
         // workgroup for every CU; QuantMapMode (the last template digit) lets the tuner force either.
-        const bool sw_ok = bits == 4 && R == 1 && mt >= 2 && (dtype == 0 || mt == 2) && (units / 16) % 2 == 0;
+        const bool sw_ok = bits == 4 && R == 1 && (dtype == 0 || mt <= 2) && (units / 16) % 2 == 0;
         int sw = 1;
         if (sw_ok && (long)(units / 32) * mtiles >= (long)num_sms) sw = 2;
+        // M <= 16: two slabs per wave as soon as the halved slab count still fills 55 % of the CUs (28672 x 8192 M = 16: 448
+        // workgroups 43.4 us, 224 workgroups 37.1; 4096 x 28672: 26.9 -> 21.1) - or on the tuner's request (digit 1)
+        if (sw_ok && mt == 1 && M <= 16 && ((long)(units / 32) * 20 >= 11L * num_sms || (template_id % 4) == 1)) sw = 2;
         if (sw_ok && bits == 4 && (template_id % 4) == 3) sw = 2;
         if (bits == 4 && (template_id % 4) == 2) sw = 1;
         if (sw_ok && ov.slabs == 2) sw = 2;

@@ -4,8 +4,10 @@
 #include "qgemm_tile.h"
 namespace flute_amd {
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw) {
-    if (sw == 2) {      // two slabs per wave: fp16 MT = 2 / 4, bf16 MT = 2
+    if (sw == 2) {      // two slabs per wave: fp16 MT = 1 / 2 / 4, bf16 MT = 1 / 2
         if (r != 1) return nullptr;
+        if (tile_p == 32 && mt == 1) return dtype == 0 ? (QGemmKernel)qgemm_tile_kernel<F16, 4, 32, 1, 1, 2> : (QGemmKernel)qgemm_tile_kernel<BF16, 4, 32, 1, 1, 2>;
+        if (tile_p == 64 && mt == 1) return dtype == 0 ? (QGemmKernel)qgemm_tile_kernel<F16, 4, 64, 1, 1, 2> : (QGemmKernel)qgemm_tile_kernel<BF16, 4, 64, 1, 1, 2>;
         if (tile_p == 32 && mt == 2) return dtype == 0 ? (QGemmKernel)qgemm_tile_kernel<F16, 4, 32, 1, 2, 2> : (QGemmKernel)qgemm_tile_kernel<BF16, 4, 32, 1, 2, 2>;
         if (tile_p == 64 && mt == 2) return dtype == 0 ? (QGemmKernel)qgemm_tile_kernel<F16, 4, 64, 1, 2, 2> : (QGemmKernel)qgemm_tile_kernel<BF16, 4, 64, 1, 2, 2>;
         if (tile_p == 32 && mt == 4 && dtype == 0) return (QGemmKernel)qgemm_tile_kernel<F16, 4, 32, 1, 4, 2>;

@@ -167,11 +167,15 @@ def test_plan_families_and_invariants():
     assert p.lds_bytes <= 160 * 1024
     rc, p = plan(4, 14336, 4096)
     assert rc == 0 and p.family == 5 and p.grid == 224
-    rc, p = plan(16, 28672, 4096)                            # 448 slabs: 1.75 rounds
-    assert rc == 0 and p.family == 5 and p.grid == 448
+    rc, p = plan(16, 28672, 4096)                            # 448 slabs: the per-wave kernel, two slabs per wave, no lane sharing
+    assert rc == 0 and p.family == 2 and (p.m_block, p.m_tiles, p.slabs_per_wave, p.grid) == (1, 1, 2, 224)
+    rc, p = plan(16, 10240, 8192)                            # 160 slabs fill 62 % of the CUs: no lane sharing either
+    assert rc == 0 and p.family == 2 and (p.m_block, p.slabs_per_wave, p.grid) == (1, 1, 160)
+    rc, p = plan(16, 4096, 4096)                             # 64 slabs: four lanes share a unit
+    assert rc == 0 and p.family == 2 and (p.m_block, p.grid) == (4, 256)
     rc, p = plan(16, 4096, 4096, tid=19)                     # QuantMapMode digit 3 at M <= 16: skinny wherever it exists
     assert rc == 0 and p.family == 5 and p.grid == 64
-    for (M, N, K, bits, tid) in ((16, 4096, 4096, 4, 16), (16, 20480, 4096, 4, 16), (17, 14336, 4096, 4, 16), (2, 14336, 4096, 4, 16),
+    for (M, N, K, bits, tid) in ((16, 4096, 4096, 4, 16), (16, 20480, 4096, 4, 16), (16, 28672, 4096, 4, 16), (17, 14336, 4096, 4, 16), (2, 14336, 4096, 4, 16),
                                  (16, 14336, 4096, 2, 0), (16, 14336, 8192, 4, 16), (16, 14336, 4096, 4, 17), (16, 14336, 4096, 4, 18),
                                  (32, 14336, 4096, 4, 19)):
         rc, p = plan(M, N, K, bits=bits, tid=tid)

@@ -385,6 +385,8 @@ def test_mfma_scale_block_and_ring_paths(env):
         (4, 32, 64, torch.float16, 2048, 1024, 100, (2, 1, 8, 4, 1, 4, 2)),       # two slabs per wave (8 column tiles)
         (4, 64, 64, torch.bfloat16, 2048 + 64, 1024, 40, (2, 1, 8, 2, 1, 2, 2)),
         (4, 32, 128, torch.float16, 4096, 512, 33, (2, 1, 4, 2, 2, 2, 2)),
+        (4, 32, 64, torch.float16, 2048, 1024, 16, (2, 1, 8, 8, 1, 1, 2)),        # one row tile x two slabs per wave (round 3: wide layers at M <= 16)
+        (4, 64, 64, torch.bfloat16, 4096 + 64, 1024, 5, (2, 1, 8, 4, 1, 1, 2)),
     ]
     for (bits, tile_p, g, dtype, K, N, M, o) in cases:
         ovr = dict(family=o[0], m_block=o[1], waves=o[2], kw=o[3], splitk=o[4], m_tiles=o[5], slabs_per_wave=o[6])
