@@ -571,12 +571,12 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const int mtiles = ceil_div(M, mt * 16);
         int R = 1;
         while (!combo_ok(R, mt)) R *= 2;
-        // One row tile (M <= 16): every workgroup pulls ALL of X through its CU, so lane sharing (R-fold more, narrower slabs)
-        // multiplies the activation traffic; it pays only while the slabs leave more than ~45 % of the CUs idle
-        // (profiles/r03/tile_lab_sw2_m16.jsonl: 10240 x 8192 M = 16, 160 slabs: R = 1 22.2 us, R = 2 26.8; 8192^2, 128 slabs:
-        // R = 2 14.7, R = 1 17.7).  Larger M: a slab per CU, as before.
-        const long fill_num = (mt == 1 && M <= 16) ? 11 : 20;      // slabs x row tiles x 20 >= fill_num x CUs: enough
-        while (combo_ok(R * 2, mt) && (long)units * R / 16 * mtiles * 20 < fill_num * num_sms * t.sms_multiple) R *= 2;
+        // Every workgroup pulls its rows of X through one CU, so lane sharing (R-fold more, narrower slabs) multiplies the
+        // activation traffic: it pays only while the workgroups leave more than ~45 % of the CUs idle (round 3,
+        // profiles/r03/tile_lab_sw2_m16.jsonl, tile_lab_sw2_m32_m128.jsonl: 10240 x 8192 M = 16, 160 slabs: R = 1 22.2 us,
+        // R = 2 26.8; M = 64: 36.7 / 49.9; 4096 x 11008 M = 64: 21.4 / 29.1; but 8192^2 M = 32, 128 slabs: R = 2 16.2, R = 1 19.3)
+        auto fills = [&](long wgs) { return wgs * 20 >= 11L * num_sms * t.sms_multiple; };
+        while (combo_ok(R * 2, mt) && !fills((long)units * R / 16 * mtiles)) R *= 2;
         // QuantMapMode digit 1 (4-bit ids): no lane sharing above M = 16 - the chip is filled by the grid K split
         // instead (8192^2 M = 64: R = 1, MT = 4, split 2 26.2 us against R = 2, MT = 2 30.3; 4096^2 prefers R = 2:
         // the tuner decides)
@@ -588,10 +588,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // workgroup for every CU; QuantMapMode (the last template digit) lets the tuner force either.
         const bool sw_ok = bits == 4 && R == 1 && (dtype == 0 || mt <= 2) && (units / 16) % 2 == 0;
         int sw = 1;
-        if (sw_ok && (long)(units / 32) * mtiles >= (long)num_sms) sw = 2;
-        // M <= 16: two slabs per wave as soon as the halved slab count still fills 55 % of the CUs (28672 x 8192 M = 16: 448
-        // workgroups 43.4 us, 224 workgroups 37.1; 4096 x 28672: 26.9 -> 21.1) - or on the tuner's request (digit 1)
-        if (sw_ok && mt == 1 && M <= 16 && ((long)(units / 32) * 20 >= 11L * num_sms || (template_id % 4) == 1)) sw = 2;
+        // ... as soon as the halved slab count still fills 55 % of the CUs (28672 x 8192 M = 16: 448 workgroups 43.4 us, 224
+        // workgroups 37.1; M = 64: 73.4 -> 54.2; 4096 x 14336 M = 128: 38.2 -> 28.2) - or, at M <= 16, on the tuner's request (digit 1)
+        if (sw_ok && (fills((long)(units / 32) * mtiles) || (mt == 1 && M <= 16 && (template_id % 4) == 1))) sw = 2;
         if (sw_ok && bits == 4 && (template_id % 4) == 3) sw = 2;
         if (bits == 4 && (template_id % 4) == 2) sw = 1;
         if (sw_ok && ov.slabs == 2) sw = 2;
