@@ -190,6 +190,67 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 0 and p.grid <= 28672 // 4
 
 
+def test_plan_invariants_over_random_shapes():
+    """Every plan the planner can hand out, over random shapes x template ids x CU counts: the launch fits the hardware and
+    the numbers a kernel derives its geometry from are consistent with the shape (what each kernel's host contract
+    says in its header).  No GPU."""
+    import random
+    from flute_amd import TEMPLATE_CONFIGS
+    lib = _lib.get()
+    p = _lib.Plan()
+    rng = random.Random(7)
+    fams = {}
+    for _ in range(6000):
+        bits = rng.choice([4, 4, 2, 3])
+        tids = [t for (b, t), c in sorted(TEMPLATE_CONFIGS.items()) if b == bits and (bits != 3 or c["TileP"] == 32)]
+        tid = rng.choice(tids)
+        tile_p = TEMPLATE_CONFIGS[(bits, tid)]["TileP"]
+        g = rng.choice([32, 64, 128, 256])
+        J = 16 if bits == 3 else 16 // bits
+        N = J * tile_p * rng.choice([1, 2, 4, 8, 16, 28, 32, 43, 56, 64, 112, 224])
+        K = rng.choice([256, 512, 1024, 2048, 3584, 4096, 4096 + 64, 5120, 8192, 11008, 14336, 28672])
+        if K % g:
+            continue
+        M = rng.choice([1, 1, 2, 3, 4, 5, 8, 16, 17, 32, 64, 128, 256, 1000, 4096])
+        num_sms = rng.choice([256, 256, 256, 304, 8, 120])
+        dtype = rng.choice([0, 1])
+        rc = lib.flute_qgemm_plan_ex(dtype, bits, g, M, N, K, tid, num_sms, 64 << 20, None, p)
+        assert rc == 0, (bits, tid, g, M, N, K, num_sms, rc)
+        key = (p.family, p.one_shot)
+        fams[key] = fams.get(key, 0) + 1
+        units = N // J
+        what = (bits, tid, g, M, N, K, num_sms, p.family, p.one_shot)
+        assert p.grid >= 1 and 64 <= p.block <= 1024 and p.block == p.waves * 64, what
+        assert 0 < p.lds_bytes <= 160 * 1024, what
+        assert p.splitk >= 1 and (p.splitk == 1 or p.workspace_needed <= 64 << 20), what
+        if p.family == 0:
+            assert M <= 4 and p.m_block >= M and p.waves % p.kw == 0, what
+            if p.one_shot == 3:                                   # persistent one-shot kernel
+                assert M <= 2 and p.kw == 1 and p.waves <= 8 and K % (512 * p.ring_depth) == 0, what
+                assert p.k_chunks * p.ring_depth * 512 == K and p.grid * p.waves * p.visits >= units, what
+                assert (K // g) % 2 == 0 and g >= 64, what
+            elif p.one_shot in (1, 2):                            # one-shot kernel
+                assert p.visits == 1 and p.splitk == 1 and (K // g) % 2 == 0 and g >= 64, what
+                assert p.grid == -(-units // (p.waves // p.kw)) and -(-(-(-K // 512)) // p.kw) <= p.ring_depth, what
+            else:
+                assert p.ring_depth in (2, 4), what
+        elif p.family == 5:                                       # skinny MFMA kernel
+            assert bits == 4 and 3 <= M <= 16 and p.splitk == 1 and p.workspace_needed == 0, what
+            assert p.ring_depth in (4, 8, 16) and p.ring_depth * p.waves * 32 == K and p.grid == N // 64, what
+            assert (K // g) % 2 == 0 and (p.ring_depth * 32) // g <= 8, what
+        elif p.family == 2:                                       # per-wave MFMA kernel
+            assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
+            assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
+            assert bits != 3 or p.m_block == 1, what
+        else:                                                     # block kernels
+            assert p.family == 3 and p.m_block in (4, 5, 9, 10, 12) and p.block == 512, what
+            assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
+            assert p.m_block != 4 or bits != 3 or p.lds_bytes == 146 * 1024, what
+    # the sweep reaches every kernel of the library
+    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (2, 0), (3, 0), (5, 0)):
+        assert fams.get(key, 0) > 0, (key, fams)
+
+
 def test_plan_rejects_bad_arguments():
     assert plan(1, 4096, 4096, bits=5)[0] == -1
     assert plan(1, 4096, 4096, g=48)[0] == -2
