@@ -1,36 +1,36 @@
-// MFMA kernel for M <= 16 (instantiated: 4 bits, one 16-row tile; written for MT tiles and 2 bits) on layers whose
-// 64-column slabs fill the chip in one round (round 3): the weights go STRAIGHT to the
-// registers of the lanes that feed them to the matrix core, every request of a wave is issued by its prologue.
-// Replaces, for these M, the per-wave kernel of qgemm_tile.h, whose operands travel through wave-private LDS rings
-// (one LDS-DMA per MFMA operand: 7.5 us at M = 16 on 4096 x 4096 against 4.1 us for M = 1).  Reference: the same
-// qgemm_device main loop (flute/csrc/qgemm_kernel.hpp:617-712) and its Stream-K fix-up of partial tiles
-// (tile_scheduler_utils.hpp:460-481), which is what the grid-level K split + last-arriver reduction below stands for.
+// MFMA kernel for 4-bit layers at M <= 16 whose 64-column slabs fill the chip in one round (round 3): weights and
+// activations go STRAIGHT to the registers of the lanes that feed them to the matrix core - no LDS staging of operands.
+// Replaces, for these M, the per-wave kernel of qgemm_tile.h, whose operands travel through wave-private LDS rings (one
+// LDS-DMA per MFMA operand).  Reference: qgemm_device's main loop (flute/csrc/qgemm_kernel.hpp:617-712); its Stream-K
+// fix-up of partial tiles (tile_scheduler_utils.hpp:460-481) is the in-workgroup K reduction below.
 //
 // Geometry.  v_mfma_f32_16x16x32: A = weights (lane (u, q): row u = l % 16, k = 8 q .. 8 q + 7), B = activations (lane
 // (j, q): row j of X, the same k), D[u][j] in lane (q, j) as rows 4 q .. 4 q + 3.  A wave owns a SLAB of 16 units (lane
 // l: unit l % 16) and D k-steps (32 k each) of it: per k-step lane (u, q) loads the 16 B of unit row u that hold k-pairs
 // 4 q .. 4 q + 3 of that step - 16 rows x 64 B per request; its four dwords are the four k-pairs, byte t of a dword the
-// pair code of column tile t (2 bits: nibble t), so the J lookups of a dword feed J MFMAs (J column tiles of 16 units)
-// against the SAME activation operand.  Activations: lane (j, q) loads its 16 B of X the same way (rows >= M: zero).
-// Per wave: 1 table + MT D activation + (J / 4) scale + D weight requests, then D x (4 J lookups, 4 J scale
-// multiplications, J MT MFMAs).
-// K is split over the KW waves of a workgroup only (LDS reduction; KW in {4, 8, 16}).  A grid-level split was built and
-// measured (profiles/r03/skinny_lab_gridsplit.jsonl): partial tiles in the workspace and a last-arriver ticket need
-// agent-scope fences, i.e. an L2 write-back per workgroup on this multi-die part - 51 us at 4 splits on 4096 x 4096
-// against 14.5 us unsplit; a second launch costs ~2 us.  So the kernel serves layers with enough slabs for the chip
-// (N >= ~10 K columns at 4 bits) and short K (<= 16 KW k-steps); the rest stays on the per-wave kernel.
-// Where the time goes (4096 x 14336, M = 16, 224 workgroups, 14.5 us; builds with parts removed, profiles/r03/
-// skinny_ablation.txt): launch + table image + reduction 4.2 us, the requests of a workgroup (131 KB of weights + 128 KB
-// of X through ONE CU) 4.1 us, the k-steps 3.9 us (as many lookups per CU as the M = 1 kernels), and they do not overlap:
-// every CU holds one workgroup whose waves all wait for the same stream.  Stamps (profiles/r03/skinny_stamps.json): the
-// 34 requests of a wave take 9 K cycles to issue, 18 K for the second wave of a SIMD - a request that touches 16 half
-// cache lines costs ~60 cycles of the CU's addresser; asking for the same bytes line-coalesced (lane l: chunk l % 4 of row
-// l / 4) and moving them to the operand lanes with ds_bpermute was measured slower (16.7 us: the requests still cost
-// ~55 cycles - the cost is per line touched - and the k-steps grow from 520 to 850 cycles).
+// pair code of column tile t, so the four lookups of a dword feed four MFMAs (four column tiles of 16 units) against the
+// SAME activation operand.  Activations: lane (j, q) loads its 16 B of X the same way (rows >= M: zero).
+// Per wave: 1 table + 1 scale + D weight + D activation requests, then D x (16 lookups, 16 scale multiplications,
+// 4 MFMAs).  (Written for MT row tiles; one is instantiated: two were no faster than the per-wave kernel.)
+// Requests: the first two k-steps before the table image is built, the rest of the first half after the barrier,
+// k-step i + D / 2 when k-step i is decoded - see the comments at issue_step.
+// K is split over the KW (4 or 8) waves of a workgroup only (LDS reduction).  A grid-level split was built and measured
+// (profiles/r03/skinny_lab_gridsplit.jsonl): partial tiles in the workspace and a last-arriver ticket need agent-scope
+// fences, i.e. an L2 write-back per workgroup on this multi-die part - 51 us at 4 splits on 4096 x 4096 against 14.5 us
+// unsplit; a second launch costs ~2 us.  So the kernel serves layers with enough slabs for the chip (N >= ~9 K columns)
+// and K = 32 D KW <= 4096; the rest stays on the per-wave kernel.
+// Where the time goes (4096 x 14336, M = 16, 224 workgroups; builds with parts removed, profiles/r03/
+// skinny_ablation.txt, all requests up front: 14.5 us): launch + table image + reduction 4.2 us, the requests of a
+// workgroup (131 KB of weights + 128 KB of X through ONE CU) 4.1 us, the k-steps 3.9 us (as many lookups per CU as the
+// M = 1 kernels).  Stamps (profiles/r03/skinny_stamps*.json): the 34 requests of a wave take 9 K cycles to issue, and the
+// second wave of a SIMD starts when the first is done - a request that touches 16 half cache lines costs ~60 cycles of the
+// CU's addresser (~270 of the SIMD's memory issue); asking for the same bytes line-coalesced (lane l: chunk l % 4 of row
+// l / 4) and moving them to the operand lanes with ds_bpermute was slower (16.7 us: the cost is per line touched, and the
+// k-steps grow from 520 to 850 cycles).  With the requests interleaved as above: 12.6 us.
 // Arithmetic: fp16 w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation in the matrix core; bf16 (no packed
 // multiply on gfx950) applies the group scale to the fp32 MFMA result of each group run, as qgemm_tile.h.
-// Host contract (api.hip: plan_skinny): 2- / 4-bit, K % (32 D) == 0, G even, group size >= 32 and D * 32 / g <= 8,
-// N % (16 J) == 0 (always: TileP >= 32), K / (32 D) <= KW.
+// Host contract (api.hip: plan_skinny): 4 bits, M <= 16, K = 32 D KW with D in {4, 8, 16} and KW in {4, 8}, G even, group
+// size >= 32 and D * 32 / g <= 8, N % 64 == 0 (always: TileP >= 32).
 #pragma once
 #include "qgemm_oneshot.h"
 #include "mfma.h"
