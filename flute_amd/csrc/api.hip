@@ -27,10 +27,12 @@ using namespace flute_amd;
 
 namespace {
 
-struct Ovr { int family, m_block, waves, kw, splitk, m_tiles, slabs, depth, one_shot; };
+// had8: set by flute_qgemm_hadamard for M <= 4 - the DECODE planners then prefer 8-wave workgroups (the fused rotation is
+// done by the workgroup's waves, 512 k each); it never reaches the MFMA planners, whose wave count is the template's
+struct Ovr { int family, m_block, waves, kw, splitk, m_tiles, slabs, depth, one_shot, had8; };
 Ovr ovr_of(const flute_overrides* o) {
-    if (!o) return Ovr{-1, -1, -1, -1, -1, -1, -1, -1, -1};
-    return Ovr{o->family, o->m_block, o->waves, o->kw, o->splitk, o->m_tiles, o->slabs_per_wave, o->ring_depth, o->one_shot};
+    if (!o) return Ovr{-1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
+    return Ovr{o->family, o->m_block, o->waves, o->kw, o->splitk, o->m_tiles, o->slabs_per_wave, o->ring_depth, o->one_shot, 0};
 }
 
 constexpr int kMaxLds = 160 * 1024;
@@ -179,7 +181,7 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
             OneShape s;
             s.W = w; s.kw = kw; s.upw = w / kw; s.pk = ceil_div(npieces, kw); s.depth = D;
             s.ipw = ceil_div(runs, w);
-            if (bits != 2 && s.ipw > 8) continue;             // a wave's table entries: one per lane
+            if (s.ipw > (bits == 2 ? 16 : 8)) continue;       // table runs a wave writes: at most 8 (2 bits: 16, four per lane group) - more would leave the image incomplete
             if (npieces * 64 > xpr * w * 64) continue;        // activations staged from registers only
             s.grid = ceil_div(units, s.upw);
             s.lds = oneshot_lds_bytes(bits, mb, D, lg, K, w);
@@ -390,6 +392,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
               StreamArgs* sa, OneArgs* oa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
+    // override families: -1 automatic, 0 decode, 1 / 2 per-wave MFMA kernel, 3 block kernels, 5 skinny MFMA kernel,
+    // 6 split-K block kernel; anything else is a caller error (round 1's family 4 is gone)
+    if (ov.family < -1 || ov.family == 4 || ov.family > 6) return FLUTE_ERR_SHAPE;
     if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
     if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
     flute_template_info t;
@@ -413,12 +418,16 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const int dec_max = 4;
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
     const bool auto_digit = (bits == 4) ? (template_id % 4) == 0 : t.sms_multiple == 1;
+    // decode planners: a fused Hadamard rotation prefers 8-wave workgroups (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with
+    // the 4-wave shape the plain product takes)
+    Ovr ovd = ov;
+    if (ov.had8 && ovd.waves < 0 && ovd.kw < 0 && ovd.one_shot != 0) ovd.waves = 8;
     auto persist_auto_ok = [&](int rows) {
         if (ov.one_shot >= 0 || ov.depth > 0 || ov.splitk > 1 || !auto_digit) return false;
         if ((size_t)N * K < ((size_t)40 << 20) || (long)units < 6L * num_sms) return false;
         flute_plan tmp;
         memset(&tmp, 0, sizeof(tmp));
-        return plan_persist(bits, lg, rows, N, K, num_sms, t, ov, &tmp, nullptr) == FLUTE_OK;
+        return plan_persist(bits, lg, rows, N, K, num_sms, t, ovd, &tmp, nullptr) == FLUTE_OK;
     };
     int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
@@ -498,8 +507,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // ring depth or grid K split means the ring kernel) or by the template (4-bit QuantMapMode digit 1, 2:
         // one-shot with 4 / 8 pieces per wave, 3: ring; 2- / 3-bit SMs_Multiple 4: one-shot, 2: ring); automatic:
         // one-shot for layers up to 64 M weights that give at least half the CUs a workgroup; one or two rows on larger layers:
-        // the persistent one-shot kernel (qgemm_persist.h; override one_shot = 2).
-        int want = ov.one_shot;
+        // the persistent one-shot kernel (qgemm_persist.h; override one_shot = 3, as flute_plan reports it, or 2).
+        int want = ov.one_shot == 3 ? 2 : ov.one_shot;       // 3 = flute_plan's code for the persistent kernel (2 kept from ABI v4)
         if (want < 0 && (ov.depth > 0 || ov.splitk > 1)) want = 0;
         if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
         if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
@@ -512,19 +521,19 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (want == 2 || persist_auto) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
-            if (plan_persist(bits, lg, M, N, K, num_sms, t, ov, &q, oa) == FLUTE_OK) { *p = q; taken = true; }
+            if (plan_persist(bits, lg, M, N, K, num_sms, t, ovd, &q, oa) == FLUTE_OK) { *p = q; taken = true; }
             else if (want == 2) want = 0;
         }
         if (!taken && want != 0) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
-            if (plan_oneshot(bits, lg, M, N, K, num_sms, t, template_id, ov, &q, oa) == FLUTE_OK &&
+            if (plan_oneshot(bits, lg, M, N, K, num_sms, t, template_id, ovd, &q, oa) == FLUTE_OK &&
                 (want == 1 || ((size_t)N * K <= ((size_t)64 << 20) && (long)q.grid * 2 >= (long)num_sms))) {
                 *p = q;
                 taken = true;
             }
         }
-        if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ov, workspace_bytes, p, sa);
+        if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ovd, workspace_bytes, p, sa);
     } else if (family == kFamilyBlock) {
         const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
@@ -782,7 +791,8 @@ static Ovr hadamard_ovr(Ovr o, int hadamard_size, int bits, int M, int N, int K)
         o.family = 0;
     // the fused rotation is done by the workgroup's waves, 512 k each: 8 waves rotate a 4096-k row in one pass
     // (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with the 4-wave shape the plain product prefers)
-    if (hadamard_size > 1 && hadamard_size <= 512 && M <= 4 && o.waves < 0 && o.kw < 0 && o.one_shot != 0) o.waves = 8;
+    // (applied inside the decode branch of the planner only: make_plan_uncached)
+    if (hadamard_size > 1 && hadamard_size <= 512 && M <= 4) o.had8 = 1;
     return o;
 }
 

@@ -81,7 +81,8 @@ typedef struct flute_plan {
     unsigned grid, block;
     size_t lds_bytes;
     size_t workspace_needed;
-    int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (2/4) */
+    int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (ring kernel 2/4; one-shot kernels: pieces per wave
+                            4/8, 3 bits 2/4; persistent one-shot kernel: pieces per segment); skinny MFMA kernel: k-steps per wave */
     int visits;          /* decode: unit groups the busiest workgroup streams */
     int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
     int one_shot;        /* decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
@@ -103,7 +104,8 @@ typedef struct flute_plan {
  *   m_tiles, slabs_per_wave   MFMA kernel: 16-row tiles per wave (1/2/4), column slabs per wave (1/2)
  *   ring_depth      decode: pieces in flight per wave (ring kernel 2/4; one-shot kernel 4/8, 3-bit 2/4); without
  *                   one_shot = 1 a given depth selects the ring kernel
- *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 2 persistent one-shot kernel (M <= 2) */
+ *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 3 persistent one-shot kernel (M <= 2) - the code
+ *                   flute_plan.one_shot reports for it; 2, ABI v4's value for the same request, is still accepted */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;

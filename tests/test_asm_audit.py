@@ -59,3 +59,6 @@ def test_audit_rules_on_synthetic_streams(tmp_path):
     assert _audit_text(tmp_path, bcast) == []
     assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[3:4], v[36:37]\n" + wait0)) == 1
     assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[4:5], v[36:37] op_sel_hi:[0,1]\n" + wait0)) == 1
+    # ... but only as THAT source: the same register named as destination or as another source is still touched
+    assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[4:5], v[3:4], v[36:37] op_sel_hi:[0,1]\n" + wait0)) == 1
+    assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[3:4], v[4:5] op_sel_hi:[0,1]\n" + wait0)) == 1

@@ -132,6 +132,65 @@ def test_tp_row_parallel_world8_fp16_partials():
     assert len(result) == world and max(result.values()) < 1e-3
 
 
+def _worker8_mlp(rank, world, port, result):
+    """The MLP pair at TP = 8, end to end: a column-parallel layer (no collective, output stays sharded) feeds a
+    row-parallel layer whose K shard is exactly that output shard; ONE all-reduce for the pair
+    (flute/integrations/vllm_utils.py:224-226, 265-326)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import flute_oracle as O
+        from flute_amd import tp
+        torch.manual_seed(0)
+        bits, tile_p, g = 4, 32, 64
+        blk = tp.columns_per_block(bits, tile_p)              # 128 columns
+        H, I, M = 512, world * blk, 3                         # hidden 512, intermediate 1024: 128 columns / 128 k per rank
+        W1 = torch.randint(0, 2 ** bits, (H, I), dtype=torch.uint8)
+        W2 = torch.randint(0, 2 ** bits, (I, H), dtype=torch.uint8)
+        Q1 = torch.from_numpy(O.pack(W1.numpy(), bits, tile_p))
+        Q2 = torch.from_numpy(O.pack(W2.numpy(), bits, tile_p))
+        S1 = (torch.randn(I, H // g) / 4).half()
+        S2 = (torch.randn(H, I // g) / 4).half()
+        table16 = torch.randn(2 ** bits).half()
+        table2 = O.make_qmap2_from_qmap(table16)
+        X = (torch.randn(M, H) / 10).half()
+        # unsharded pair through the oracle (fp16 hand-off between the layers, as the product)
+        h_full = O.qgemm(X, Q1.numpy(), S1, table16, table2, bits, g, tile_p).half()
+        y_full = O.qgemm(h_full, Q2.numpy(), S2, table16, table2, bits, g, tile_p).float()
+
+        calls = {"all_reduce": 0, "all_gather": 0}
+        real_ar, real_ag = dist.all_reduce, dist.all_gather
+        dist.all_reduce = lambda *a, **k: (calls.__setitem__("all_reduce", calls["all_reduce"] + 1), real_ar(*a, **k))[1]
+        dist.all_gather = lambda *a, **k: (calls.__setitem__("all_gather", calls["all_gather"] + 1), real_ag(*a, **k))[1]
+        tp.local_qgemm = lambda x, Qs, Ss, t, t2, b, gs, tid: O.qgemm(x, Qs.numpy(), Ss, t, t2, b, gs, tile_p).half()
+        up = tp.ColumnParallelQLinear.from_full(Q1, S1, table16, table2, bits, g, 0, tile_p, gather_output=False)
+        down = tp.RowParallelQLinear.from_full(Q2, S2, table16, table2, bits, g, 0)
+        h = up(X)                                             # [M, I / world], no collective
+        assert h.shape == (M, I // world) and calls == {"all_reduce": 0, "all_gather": 0}
+        assert torch.equal(h, h_full[:, rank * I // world:(rank + 1) * I // world]), "the column shard IS the row layer's K shard"
+        y = down(h)                                           # fp16 partials, one all-reduce
+        assert calls == {"all_reduce": 1, "all_gather": 0}
+        err = ((y.float() - y_full).norm() / y_full.norm()).item()
+        assert err < 1e-3, err
+        result[rank] = err
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp_mlp_pair_world8_one_allreduce():
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    result = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker8_mlp, args=(r, world, port, result)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert len(result) == world and max(result.values()) < 1e-3
+
+
 def test_shard_bounds_rejected():
     from flute_amd import tp
     Q = torch.zeros((4 * 128 // 16, 128), dtype=torch.int16)

@@ -64,34 +64,38 @@ def _sgpr_mentions(text, n):
     return True, hits[0] and not any(hits[1:]) and not ops[0].startswith(("s_cmp", "s_cbranch", "s_bitcmp"))
 
 
-def _pk_f32_unread(text):
-    """VGPRs a packed-fp32 instruction names but does not read: `v_pk_mul_f32 d, v[a:a+1], v[b:b+1] op_sel_hi:[0,1]`
-    takes BOTH halves of source 0 from v[a] (op_sel picks the register of the low result, op_sel_hi of the high one;
-    defaults [0,..] / [1,..]) - hipcc uses this to broadcast a scalar held in the low register of a pair whose high
-    register belongs to something else."""
+def _pk_f32_used(text, regs_of):
+    """Registers a packed-fp32 instruction really touches, operand by operand, or None for any other instruction.
+    `v_pk_mul_f32 d, v[a:a+1], v[b:b+1] op_sel_hi:[0,1]` takes BOTH halves of source 0 from v[a] (op_sel picks the
+    register of the low result, op_sel_hi of the high one; defaults [0,..] / [1,..]) - hipcc uses this to broadcast a
+    scalar held in the low register of a pair whose high register belongs to something else.  Only the unread half of
+    THAT source operand is dropped: the destination and the other sources stay in the set even when they name the
+    same register."""
     m = re.match(r"v_pk_(?:mul|add|fma)_f32\s+(.*)$", text)
     if not m:
-        return set()
+        return None
     body = m.group(1)
     mods = {"op_sel": None, "op_sel_hi": None}
     for name in mods:
         mm = re.search(name + r":\[([01,]+)\]", body)
         if mm:
             mods[name] = [int(x) for x in mm.group(1).split(",")]
-    ops = [o.strip() for o in re.sub(r"\s+op_sel(_hi)?:\[[01,]+\]", "", body).split(",")]
-    unread = set()
+    # operands are separated by commas outside brackets (v[4:5] has none, but be strict)
+    ops = [o.strip() for o in re.split(r",(?![^\[]*\])", re.sub(r"\s+op_sel(_hi)?:\[[01,]+\]", "", body))]
+    used = set(regs_of(ops[0]))                                # destination
     for i, o in enumerate(ops[1:]):                            # sources
+        r = set(regs_of(o))
         mm = re.match(r"v\[(\d+):(\d+)\]$", o)
-        if not mm or int(mm.group(2)) != int(mm.group(1)) + 1:
-            continue
-        lo_sel = mods["op_sel"][i] if mods["op_sel"] and i < len(mods["op_sel"]) else 0
-        hi_sel = mods["op_sel_hi"][i] if mods["op_sel_hi"] and i < len(mods["op_sel_hi"]) else 1
-        picked = {lo_sel, hi_sel}
-        if 0 not in picked:
-            unread.add(int(mm.group(1)))
-        if 1 not in picked:
-            unread.add(int(mm.group(2)))
-    return unread
+        if mm and int(mm.group(2)) == int(mm.group(1)) + 1:
+            lo_sel = mods["op_sel"][i] if mods["op_sel"] and i < len(mods["op_sel"]) else 0
+            hi_sel = mods["op_sel_hi"][i] if mods["op_sel_hi"] and i < len(mods["op_sel_hi"]) else 1
+            picked = {lo_sel, hi_sel}
+            if 0 not in picked:
+                r.discard(int(mm.group(1)))
+            if 1 not in picked:
+                r.discard(int(mm.group(2)))
+        used |= r
+    return used
 
 
 def _dead_readfirstlane(lines, i, text):
@@ -185,7 +189,8 @@ def audit(path):
             busy |= r
         for _, r in ds_set:
             busy |= r
-        hit = (used - _pk_f32_unread(text)) & busy
+        pk = _pk_f32_used(text, regs_of)
+        hit = (used if pk is None else pk) & busy
         if hit and not _dead_readfirstlane(all_lines, ln - 1, text):
             findings.append((kernel, ln, text, sorted(hit)))
     return findings
