@@ -26,7 +26,7 @@ class Plan(ctypes.Structure):
         ("splitk", c_int), ("k_per_split", c_int), ("lut_copies", c_int),
         ("grid", ctypes.c_uint), ("block", ctypes.c_uint),
         ("lds_bytes", c_size_t), ("workspace_needed", c_size_t),
-        ("ring_depth", c_int), ("visits", c_int), ("k_chunks", c_int), ("one_shot", c_int)]
+        ("ring_depth", c_int), ("visits", c_int), ("k_chunks", c_int), ("one_shot", c_int), ("splitk_mode", c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -76,7 +76,7 @@ def get() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.flute_abi_version() != 4:
+        if lib.flute_abi_version() != 5:
             raise ImportError("flute_amd: ABI version mismatch, rebuild libflute_amd.so")
         _lib = lib
     return _lib

@@ -22,6 +22,7 @@
 #include "mfma.h"
 #include "qgemm_tile.h"
 #include "qgemm_block.h"
+#include "qgemm_splitk.h"
 
 using namespace flute_amd;
 
@@ -38,6 +39,10 @@ Ovr ovr_of(const flute_overrides* o) {
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
 constexpr int kFamilySkinny = 5;                // registers-only MFMA kernel for 3 <= M <= 32 (qgemm_skinny.h)
+constexpr int kFamilySplitK = 6;                // 128 x 128 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
+// Workspace layout (every kernel): [0, kXwgFlagBytes) tile state words of the in-launch reductions (xwg.h; zero between
+// calls), fp32 slabs behind them.  A planner sees the room behind the state words only.
+size_t slab_room(size_t workspace_bytes) { return workspace_bytes > kXwgFlagBytes ? workspace_bytes - kXwgFlagBytes : 0; }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
@@ -304,6 +309,54 @@ int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, flute_plan
     return FLUTE_OK;
 }
 
+// Split-K block kernel (qgemm_splitk.h): 128 x 128 tiles x `splitk` K slices, one workgroup each; the slices of a tile are
+// neighbours in the block order (dispatched together), the row tiles of a column tile follow each other.  Legal splits:
+// K / splitk a multiple of 2 x max(64, group) (two K halves per workgroup, each whole 64-k steps and whole groups), at
+// most four 8-group scale blocks per K half, slabs + state words inside the workspace.  Cost model (us, measured on
+// MI355X, profiles/r04/splitk_lab*.jsonl): rounds x (fixed + steps x per-step) + seam.
+int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& ov, size_t workspace_bytes, flute_plan* p) {
+    if (bits != 2 && bits != 4) return FLUTE_ERR_SHAPE;
+    const int g = 1 << lg, G = K >> lg;
+    if (G % 8 || N % 128 || K % 128) return FLUTE_ERR_SHAPE;
+    if ((size_t)(M + 128) * K * 2 >= (size_t)0xfffffff0u || (size_t)N * G * 2 >= (size_t)0xfffffff0u) return FLUTE_ERR_SHAPE;
+    const long tiles = (long)ceil_div(M, 128) * (N / 128);
+    if (tiles > kXwgMaxTiles) return FLUTE_ERR_SHAPE;
+    const int align = 2 * std::max(64, g);
+    auto legal = [&](int sk) {
+        if (sk < 1 || sk > 16 || K % sk || (K / sk) % align) return false;
+        const int gh = (K / sk / 2) >> lg;                     // groups per K half
+        if (gh + ((gh % 8) ? 7 : 0) > 32) return false;
+        if (sk > 1 && ((size_t)sk * M * N * 4 > slab_room(workspace_bytes) || (size_t)sk * M * N * 4 >= ((size_t)1 << 31))) return false;
+        return true;
+    };
+    int best = 0;
+    if (ov.splitk > 0) {
+        if (!legal(ov.splitk)) return FLUTE_ERR_SHAPE;
+        best = ov.splitk;
+    } else {
+        double best_us = 1e30;
+        for (int sk = 1; sk <= 16; ++sk) {
+            if (!legal(sk)) continue;
+            const long wgs = tiles * sk;
+            const long rounds = (wgs + num_sms - 1) / num_sms;
+            const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
+            const double seam = sk == 1 ? 0.0 : ((sk == 2 || sk == 4) ? 3.5 : 3.0 + 1.0 * sk);
+            const double us = rounds * (2.5 + steps * 0.85) + seam;
+            if (us < best_us) { best_us = us; best = sk; }
+        }
+        if (!best) return FLUTE_ERR_SHAPE;
+    }
+    memset(p, 0, sizeof(*p));
+    p->family = kFamilySplitK;
+    p->m_block = 0; p->m_tiles = 8; p->slabs_per_wave = 1; p->waves = 8; p->kw = 2;
+    p->splitk = best; p->k_per_split = K / best;
+    p->grid = (unsigned)(tiles * best); p->block = 512;
+    p->lds_bytes = (size_t)splitk_lds_bytes(bits); p->lut_copies = 32;
+    p->splitk_mode = best > 1 ? 1 : 0;
+    p->workspace_needed = best > 1 ? (size_t)best * M * N * 4 + kXwgFlagBytes : 0;
+    return FLUTE_OK;
+}
+
 int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, const flute_template_info& t,
                 const Ovr& ov, size_t workspace_bytes, flute_plan* p, StreamArgs* sa) {
     const int J = (bits == 3) ? 16 : 16 / bits;
@@ -449,6 +502,12 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             memset(p, 0, sizeof(*p));
         }
     }
+    // Split-K block kernel (qgemm_splitk.h): by override (family 6)
+    if (ov.family == kFamilySplitK) {
+        const int src = plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p);
+        if (src == FLUTE_OK && p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
+        return src;
+    }
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
     // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks); scale rows in
     // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
@@ -533,7 +592,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 taken = true;
             }
         }
-        if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ovd, workspace_bytes, p, sa);
+        if (!taken) rc = plan_stream(dtype, bits, lg, M, N, K, num_sms, t, ovd, slab_room(workspace_bytes), p, sa);
     } else if (family == kFamilyBlock) {
         const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
@@ -543,7 +602,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             while ((long)tiles_m * tiles_n * splitk * 2 <= (long)num_sms && K / (splitk * 2) >= std::max(256, align_k)) splitk *= 2;
         int kps = round_up(ceil_div(K, splitk), align_k);
         splitk = ceil_div(K, kps);
-        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > slab_room(workspace_bytes)) {
             splitk >>= 1;
             kps = round_up(ceil_div(K, splitk), align_k);
             splitk = ceil_div(K, kps);
@@ -628,7 +687,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (ov.splitk > 0) splitk = ov.splitk;
         int kps = round_up(ceil_div(K, splitk), 32 * kw);
         splitk = ceil_div(K, kps);
-        while (splitk > 1 && (size_t)splitk * M * N * 4 > workspace_bytes) {
+        while (splitk > 1 && (size_t)splitk * M * N * 4 > slab_room(workspace_bytes)) {
             splitk >>= 1;
             kps = round_up(ceil_div(K, splitk), 32 * kw);
             splitk = ceil_div(K, kps);
@@ -642,7 +701,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         p->lut_copies = 32;
     }
     if (rc) return rc;
-    p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 : 0;
+    p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 + kXwgFlagBytes : 0;
     if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
     return FLUTE_OK;
 }
@@ -919,7 +978,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     if (p.family == 0) {
         sa.A = A; sa.Q = reinterpret_cast<const uint32_t*>(Q); sa.D = D; sa.S = S;
         sa.QM2 = reinterpret_cast<const uint32_t*>(QM2);
-        sa.partial = reinterpret_cast<float*>(workspace);
+        sa.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
         sa.had_log = had_log; sa.had_scale = had_scale; sa.m0 = 0;
         StreamKernel fn = pick_stream_kernel(num_bits, dtype, t.tile_p, p.m_block, p.ring_depth, 0);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
@@ -935,12 +994,34 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         return FLUTE_OK;
     }
 
+    if (p.family == kFamilySplitK) {
+        SplitKArgs b;
+        memset(&b, 0, sizeof(b));
+        b.A = A; b.Q = reinterpret_cast<const uint32_t*>(Q); b.D = D; b.S = S;
+        b.QM2 = reinterpret_cast<const uint32_t*>(QM2);
+        b.state = reinterpret_cast<uint32_t*>(workspace);
+        b.partial = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes) : nullptr;
+        b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
+        b.tiles_m = ceil_div(M, 128);
+        b.splitk = p.splitk; b.k_per_split = p.k_per_split;
+        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        void* kargs[] = {&b};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
+
     if (p.family == kFamilyBlock) {
         BlockArgs b;
         memset(&b, 0, sizeof(b));
         b.A = A; b.Q = reinterpret_cast<const uint32_t*>(Q); b.D = D; b.S = S;
         b.QM2 = reinterpret_cast<const uint32_t*>(QM2);
-        b.partial = reinterpret_cast<float*>(workspace);
+        b.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
         const int bm = block_rows(p.m_block);
         b.tiles_m = ceil_div(M, bm); b.tiles_n = N / 256;
@@ -965,7 +1046,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     QGemmArgs a;
     a.A = A; a.Q = reinterpret_cast<const uint32_t*>(Q); a.D = D; a.S = S;
     a.QM2 = reinterpret_cast<const uint32_t*>(QM2);
-    a.partial = reinterpret_cast<float*>(workspace);
+    a.partial = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes) : nullptr;
     a.M = M; a.N = N; a.K = K; a.G = K / group_size;
     a.lg = ilog2(group_size);
     a.units = N / ((num_bits == 3) ? 16 : 16 / num_bits);

@@ -1,0 +1,442 @@
+// Split-K block kernel (round 4): 128 x 128 output tiles, K split over workgroups, partial tiles combined INSIDE the launch.
+//
+// The chip-filling schedule for 128 <= M <= ~1024 on 4096-wide layers that rounds 2 and 3 lacked: the reference's Stream-K
+// hands every CTA an equal share of tiles_M x tiles_N x tiles_K for any M (flute/csrc/tile_scheduler_utils.hpp:460-481,
+// fix-up :58-211, main loop qgemm_kernel.hpp:617-712).  Here M = 256 on 4096 x 4096 is 2 x 32 tiles of 128 x 128, each
+// cut four ways in K: 256 workgroups, one per CU, 1024 k each; the four partial tiles of an output tile meet through the
+// workspace with write-through stores and one arrival word (xwg.h) - no second launch, no release fence.
+//
+// Workgroup = 8 waves = 4 column groups (32 columns = two MFMA column tiles each, as qgemm_block2.h) x 2 K halves: the
+// waves of K half g run the block2 pipeline on the contiguous half [g kps / 2, (g + 1) kps / 2) of the workgroup's K
+// range with their own three 64-k activation stages; every weight of the workgroup's range is dequantised exactly once
+// (8 lookups + 8 multiplies per 16 MFMAs of a 32-k half step), a wave holds 8 row tiles x 2 column tiles = 64
+// accumulator registers.  Differences from qgemm_block2.h, all aimed at the short (8-step) main loop of this regime:
+//   * activation pieces are 8 rows x 128 B - WHOLE cache lines (a request is priced per line it touches:
+//     tools/stamps_skinny.py; block2's pieces are 16 rows x 64 B); fragment swizzle sk_swz (= qgemm_tile.h's swz_x);
+//   * the wave's scales for its whole K half are fetched once, by the prologue (<= 32 groups x 32 columns = 2 KB per
+//     wave): no scale request - and no sink request - per step;
+//   * a step's requests are 4 activation pieces + 2 weight pieces per wave, riding between the MFMAs of half step 0.
+// Epilogue: (1) the two K halves exchange half of their row tiles through LDS (every wave ends with 4 row tiles x 2 column
+// tiles of the workgroup's K range), (2) splitk > 1: the E form of xwg.h when splitk is 2 or 4 (slice s owns row tile
+// s, s + nsh, ... of every wave), the L form otherwise; sums are taken in a fixed order (owner first, then the other slices
+// ascending; L: all slices ascending), so the result does not depend on arrival order.
+// Arithmetic contract as qgemm_block2.h: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation, one rounding.
+// Host contract (api.hip, plan_splitk): 2 or 4 bits, G % 8 == 0, K % k_per_split == 0, k_per_split % (2 * max(64, g)) == 0,
+// at most 32 scale groups (+ alignment slack: four 8-group blocks) per K half, splitk * M * N * 4 < 2^31.
+#pragma once
+#include <utility>
+
+#include "qgemm_block.h"
+#include "xwg.h"
+
+namespace flute_amd {
+
+struct SplitKArgs {
+    const void* A;          // [M,K] T
+    const uint32_t* Q;      // [P,K/2] packed
+    void* D;                // [M,N] T
+    const void* S;          // [N,G] T
+    const uint32_t* QM2;    // [4^b] pair table
+    float* partial;         // [splitk][M][N] fp32 slabs (write-through), splitk > 1
+    uint32_t* state;        // two words per output tile, zero before and after the launch (xwg.h)
+    int M, N, K, G, lg;
+    int tiles_m;            // 128-row tiles (fastest in the block order: the row tiles of a column tile are neighbours)
+    int splitk, k_per_split;
+};
+
+constexpr int SK_RT = 8;                                           // row tiles per workgroup (128 rows)
+constexpr int SK_STAGE = SK_RT * 2 * 1024;                         // 128 rows x 64 k: 16 pieces of 1 KB
+constexpr int SK_SCALE_WAVE = 2048;                                // four 8-group blocks x 32 columns x 16 B
+// position swizzle of an 8-row x 8-chunk activation piece (rows 8 rh .. 8 rh + 7 of a 16-row tile): the 16 lanes of every
+// ds_read_b128 lane group hit 16 different 16-B slots of the 256-B bank row (as qgemm_tile.h's swz_x; checked for the
+// lane groups of MI355X_MICROARCH.md's LDS table by tests/test_host.py)
+__host__ __device__ constexpr int sk_swz(int row8, int rh) { return (row8 >> 1) | (rh << 2); }
+__host__ __device__ constexpr int splitk_lds_bytes(int bits) {
+    return (128 << (2 * bits)) + 2 * BLK_STAGES * SK_STAGE + 8 * SK_SCALE_WAVE;
+}
+
+template <typename T, int TILEP, int BITS = 4>
+__global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args) {
+    using NT = Num<T>;
+    static_assert(BITS == 4 || BITS == 2, "3-bit layers: qgemm_block3.h / qgemm_tile.h");
+    constexpr int J = 16 / BITS;
+    constexpr int U = 32 / J;                                      // units per wave (32 columns)
+    constexpr int FPT = 16 / U;                                    // fields per column tile and unit
+    constexpr int FB = 2 * BITS;
+    constexpr int RT = SK_RT, NT2 = 2, NWN = 4;
+    constexpr int PPW = RT * 2 / NWN;                              // activation pieces per wave and step (4)
+    constexpr int BATCH = PPW + 2;                                 // + two weight pieces
+    static_assert(BATCH <= RT, "one request per row tile of half step 0");
+    constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
+    constexpr int X_BASE = LUT_BYTES;
+    constexpr int SC_BASE = X_BASE + 2 * BLK_STAGES * SK_STAGE;
+
+    SplitKArgs a = args;
+    {
+#define FLUTE_OPAQUE(x) asm volatile("" : "+s"(x))
+        FLUTE_OPAQUE(a.A); FLUTE_OPAQUE(a.Q); FLUTE_OPAQUE(a.D); FLUTE_OPAQUE(a.S); FLUTE_OPAQUE(a.QM2);
+        FLUTE_OPAQUE(a.partial); FLUTE_OPAQUE(a.state); FLUTE_OPAQUE(a.M); FLUTE_OPAQUE(a.N); FLUTE_OPAQUE(a.K);
+        FLUTE_OPAQUE(a.G); FLUTE_OPAQUE(a.lg); FLUTE_OPAQUE(a.tiles_m); FLUTE_OPAQUE(a.splitk); FLUTE_OPAQUE(a.k_per_split);
+#undef FLUTE_OPAQUE
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (lds_base_of(smem) != 0) __builtin_trap();
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r16 = lane & 15;
+    const int q4 = lane >> 4;
+    const int u8 = r16 % U;
+    const int fsel = r16 / U;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave & 3;                                       // column group
+    const int kh = wave >> 2;                                      // K half
+
+    int tile = blockIdx.x, split = 0;
+    if (a.splitk > 1) { split = tile % a.splitk; tile /= a.splitk; }
+    const int tm_idx = tile % a.tiles_m, tn_idx = tile / a.tiles_m;
+    const int m0 = tm_idx * (RT * 16);
+    const int unit0 = (tn_idx * NWN + wg) * U;
+    const int khalf = a.k_per_split >> 1;
+    const int kbeg = split * a.k_per_split + kh * khalf;           // this wave's K range: [kbeg, kbeg + khalf)
+    const int nsteps = khalf >> 6;
+    const uint32_t row_bytes = (uint32_t)a.K * 2u;
+
+    const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
+    const srd_t w_srd = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit0 * row_bytes, (uint32_t)U * row_bytes);
+    const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
+
+    // ---- activation pieces: piece p = 2 rt + rh of a stage = rows 16 rt + 8 rh .. + 7, 128 B (the 64 k of the step) each;
+    // lane L fetches the 16-B chunk (L & 7) ^ sk_swz(L >> 3, rh) of row L >> 3 and the DMA writes it lane-linearly, so LDS
+    // position pos of row8 holds chunk pos ^ swz.  This wave's pieces: 4 wg .. 4 wg + 3 (row tiles 2 wg, 2 wg + 1).
+    // Rows past M: their byte offset is past the descriptor's range and reads as zero (voffset is what is checked).
+    const int row8 = lane >> 3;
+    uint32_t x_vo[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int rt = wg * 2 + (i >> 1), rh = i & 1;
+        x_vo[i] = (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ sk_swz(row8, rh)) * 8)) * 2);
+    }
+    const uint32_t x_grp = (uint32_t)X_BASE + (uint32_t)kh * (BLK_STAGES * SK_STAGE);      // this K half's three stages
+    const uint32_t x_lds0 = x_grp + (uint32_t)(wg * PPW) * 1024u;
+    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)q4 * 16u;
+
+    u32x4_t w[BLK_STAGES][2];
+    // batch u = the hidden loads of this wave's K step u; batches past the end (issued two steps ahead, never consumed)
+    // re-read the last step.  Every K offset is wave-uniform and travels in the scalar offset.
+    auto issue_one = [&](auto slot_tag, auto i_tag, int u) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int i = decltype(i_tag)::value;
+        const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
+        if constexpr (i < PPW) dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * SK_STAGE);
+        else w[slot][i - PPW] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)(i - PPW) * 64u);
+    };
+    auto issue_batch = [&](auto slot_tag, int u) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (issue_one(slot_tag, std::integral_constant<int, I>{}, u), ...);
+        }(std::make_integer_sequence<int, BATCH>{});
+    };
+
+    // ---- scales of the whole K half, once: 8-group blocks from the block that holds the first group.  Request r, lane L:
+    // block 2 r + L / 32 of column (unit L % U, field (L & 31) / U); image [block][column] x 16 B, lane-linear ----
+    const int g0e = (kbeg >> a.lg) & ~7;
+    const uint32_t sc_base = (uint32_t)SC_BASE + (uint32_t)wave * SK_SCALE_WAVE;
+    {
+        const int cl = lane & 31;
+        const uint32_t s_v = (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (cl % U)) + (cl / U) * TILEP) * a.G + g0e + (lane >> 5) * 8) * 2);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) dma16_buf(s_v, s_srd, (uint32_t)r * 32u, sc_base + (uint32_t)r * 1024u);
+    }
+    issue_batch(std::integral_constant<int, 0>{}, 0);
+    issue_batch(std::integral_constant<int, 1>{}, 1);
+    {
+        constexpr int ENT = 1 << (2 * BITS);
+        for (int p = tid; p < ENT * 8; p += 512) {
+            const uint32_t v = a.QM2[p >> 3];
+            *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(v, v, v, v);
+        }
+    }
+    const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
+    // fragment of row tile R, half step h, stage slot: x_grp + slot * SK_STAGE + R * 2048 + piece (r16 >> 3) * 1024 + row
+    // (r16 & 7) * 128 + position ((4 h + q4) ^ swz) * 16; the lane part lives in two base registers, the rest is immediate
+    const uint32_t frag_b0 = x_grp + (uint32_t)((r16 >> 3) * 1024 + (r16 & 7) * 128 + ((q4 ^ sk_swz(r16 & 7, r16 >> 3)) * 16));
+    const uint32_t frag_b1 = x_grp + (uint32_t)((r16 >> 3) * 1024 + (r16 & 7) * 128 + (((4 + q4) ^ sk_swz(r16 & 7, r16 >> 3)) * 16));
+    const uint32_t sc_lane = sc_base + (uint32_t)(fsel * U + u8) * 16u;
+    const uint32_t shift0 = (uint32_t)(fsel * FB);
+
+    f32x4_t acc[RT][NT2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t v[8];                                                 // hidden lookups of the NEXT half step: [tile][word]
+    u32x4_t af[RT];                                                // fragment slots (row tile R lives in slot R)
+    uint32_t scn[NT2];                                             // scales of the next half step
+
+    auto scales = [&](int t, int h) {
+        const int rel = ((kbeg + t * 64 + h * 32) >> a.lg) - g0e;
+        const uint32_t sb = sc_lane + (uint32_t)(rel >> 3) * 512u + (uint32_t)(rel & 7) * 2u;
+        uint32_t& d0 = scn[0];
+        uint32_t& d1 = scn[1];
+        asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
+        asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");     // field + FPT = 16 image columns on
+    };
+    auto lookup = [&](const u32x4_t& qw, auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;                  // tile n / 4, word n % 4
+        const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(FB * FPT * (n >> 2)), (uint32_t)FB);
+        v[n] = lds_lookup32((idx << 7) | lane_off);
+    };
+    auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
+        constexpr int R = decltype(r_tag)::value;
+        constexpr int h = decltype(h_tag)::value;
+        constexpr int off = decltype(slot_tag)::value * SK_STAGE + R * 2048;
+        static_assert(off < 65536, "ds_read_b128 immediate offset");
+        u32x4_t& dst = af[R];
+        const uint32_t addr = h == 0 ? frag_b0 : frag_b1;          // (named outside the asm: a generic lambda captures no variable it only meets as an asm operand)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+    };
+    auto wait_lds = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                       "+v"(scn[0]), "+v"(scn[1])
+                     : : "memory");
+    };
+
+    auto half = [&](auto slot_tag, auto h_tag, int t) {
+        constexpr int slot = decltype(slot_tag)::value;
+        constexpr int h = decltype(h_tag)::value;
+        constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;
+        constexpr int nh = h ^ 1;
+        wait_lds();
+        if constexpr (h == 0) {
+            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free: batch t+2 follows, spread over the rows
+        } else {
+            // (B) batch t+1 has landed once at most batch t+2 is outstanding
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        u32x4_t bf[NT2];
+#pragma unroll
+        for (int c = 0; c < NT2; ++c) {
+            const uint32_t sj = scn[c];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], sj);
+        }
+        scales(t + h, nh);
+        const u32x4_t qw = w[nslot][nh];
+        auto row = [&](auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+#pragma unroll
+            for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
+            if constexpr (h == 0 && R < BATCH)
+                issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, r_tag, t + 2);
+            // the next half step's fragment of this row tile replaces the one just multiplied; one lookup rides along
+            frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
+            lookup(qw, r_tag);
+        };
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (row(std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, RT>{});
+    };
+
+    // scales, batch 0 and the pair table before anyone reads them
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(BATCH) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    scales(0, 0);
+    {
+        const u32x4_t qw = w[0][0];
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, RT>{});
+        [&]<int... L>(std::integer_sequence<int, L...>) {
+            (lookup(qw, std::integral_constant<int, L>{}), ...);
+        }(std::make_integer_sequence<int, 8>{});
+    }
+    auto step = [&](auto slot_tag, int t) {
+        half(slot_tag, std::integral_constant<int, 0>{}, t);
+        half(slot_tag, std::integral_constant<int, 1>{}, t);
+    };
+    for (int t0 = 0;; t0 += BLK_STAGES) {
+        step(std::integral_constant<int, 0>{}, t0);
+        if (t0 + 1 >= nsteps) break;
+        step(std::integral_constant<int, 1>{}, t0 + 1);
+        if (t0 + 2 >= nsteps) break;
+        step(std::integral_constant<int, 2>{}, t0 + 2);
+        if (t0 + 3 >= nsteps) break;
+    }
+    wait_lds();                                                    // the prefetch past the end
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
+
+    // ---- epilogue 1: the K halves swap half of their row tiles through LDS (K half 0 keeps row tiles 0..3, K half 1
+    // keeps 4..7); own[i][t] = row tile 4 kh + i over the workgroup's whole K range ----
+    f32x4_t own[4][NT2];
+    {
+        __syncthreads();                                           // every wave is done with the stages
+        float4* xb = reinterpret_cast<float4*>(smem + X_BASE);     // [wave][4 row tiles][2 column tiles][64 lanes] x 16 B = 64 KB
+        auto put = [&](int i, int t, const f32x4_t s) { xb[((wave * 4 + i) * NT2 + t) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]); };
+        auto get = [&](int i, int t) { const float4 p = xb[(((wave ^ 4) * 4 + i) * NT2 + t) * 64 + lane]; return f32x4_t{p.x, p.y, p.z, p.w}; };
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) put(i, t, acc[4 + i][t]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) put(i, t, acc[i][t]);
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) own[i][t] = acc[i][t] + get(i, t);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) own[i][t] = get(i, t) + acc[4 + i][t];       // K half 0 first in both waves: one order
+        }
+    }
+
+    // ---- epilogue 2: accumulator register j of lane (r16, q4) = weight row 4 q4 + j of the column tile = unit
+    // (4 q4 + j) % U, field (4 q4) / U + FPT t: four consecutive columns; the lane's output row is r16 ----
+    const int c_unit = unit0 + (4 * q4) % U;
+    uint32_t col[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) col[t] = (uint32_t)(unit_col0<BITS, TILEP>(c_unit) + ((4 * q4) / U + FPT * t) * TILEP);
+    const int row_base = m0 + kh * 64 + r16;                       // + 16 i
+    auto store_d = [&](int i, int t, const f32x4_t o4) {
+        const int row = row_base + 16 * i;
+        if (row < a.M) {
+            uint2 o;
+            o.x = (uint32_t)NT::from_float(o4[0]) | ((uint32_t)NT::from_float(o4[1]) << 16);
+            o.y = (uint32_t)NT::from_float(o4[2]) | ((uint32_t)NT::from_float(o4[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col[t]) = o;
+        }
+    };
+    if (a.splitk == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) store_d(i, t, own[i][t]);
+        return;
+    }
+
+    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(a.partial, (uint32_t)((size_t)a.splitk * a.M * a.N * 4));
+    const uint32_t slab_bytes = (uint32_t)((size_t)a.M * a.N * 4);
+    // byte offset of (slice, row tile i, column tile t) of this lane; rows past M: past the descriptor (stores dropped, loads 0)
+    auto slab_off = [&](int slice, int i, int t) {
+        const int row = row_base + 16 * i;
+        return (row < a.M) ? (uint32_t)slice * slab_bytes + (uint32_t)(((size_t)row * a.N + col[t]) * 4) : 0xfffffff0u;
+    };
+    xwg_word* st = xwg_state(a.state + 2 * tile);
+    const uint32_t bcast = 0;                                      // LDS dword 0 (the pair table is dead)
+    const int nsl = a.splitk;
+
+    // E form for NSH = 2, 4 shares (share q = row tiles q, q + NSH, ... of every wave), PER = 4 / NSH row tiles per share
+    auto e_form = [&]<int NSH>(std::integral_constant<int, NSH>) {
+        constexpr int PER = 4 / NSH;
+        const int me = split;
+        f32x4_t mine[PER][NT2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i % NSH == me) {                                   // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) mine[i / NSH][t] = own[i][t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) xwg_store(own[i][t], slab, slab_off(me, i, t));
+            }
+        }
+        // share `sh`: first + the other slices' partials in ascending slice order -> D
+        auto combine = [&](int sh, const f32x4_t (&first)[PER][NT2]) {
+            f32x4_t ld[PER][NT2][NSH - 1];
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t)
+#pragma unroll
+                    for (int o = 0; o < NSH - 1; ++o) {
+                        const int s2 = o + (o >= sh ? 1 : 0);      // the o-th slice other than the owner
+                        ld[jj][t][o] = xwg_load(slab, slab_off(s2, sh + jj * NSH, t));
+                    }
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) {
+                    f32x4_t s = first[jj][t];
+#pragma unroll
+                    for (int o = 0; o < NSH - 1; ++o) s += ld[jj][t][o];
+                    store_d(sh + jj * NSH, t, s);
+                }
+        };
+        const uint32_t before = xwg_arrive(st, bcast, tid);
+        if (before == (uint32_t)(NSH - 1)) {
+            combine(me, mine);
+            const uint32_t ab = xwg_sweep(st, NSH, me, bcast, tid);
+            for (int q = 0; q < NSH; ++q) {
+                if (!((ab >> q) & 1u)) continue;                   // abandoned by its owner: every slice's partial of it is in place
+                f32x4_t first[PER][NT2];
+#pragma unroll
+                for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) first[jj][t] = xwg_load(slab, slab_off(q, q + jj * NSH, t));
+                combine(q, first);
+            }
+            xwg_reset(st, tid);
+        } else if (xwg_wait_all(st, NSH, bcast, tid)) {
+            xwg_claim(st, me, tid);
+            combine(me, mine);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) xwg_store(mine[jj][t], slab, slab_off(me, me + jj * NSH, t));
+            xwg_abandon(st, me, tid);
+        }
+    };
+
+    if (nsl == 4) {
+        e_form(std::integral_constant<int, 4>{});
+    } else if (nsl == 2) {
+        e_form(std::integral_constant<int, 2>{});
+    } else {
+        // L form: every slice publishes its whole partial; the last arriver sums ALL slices in ascending order (its own
+        // from the slab as well: one order whoever is last)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) xwg_store(own[i][t], slab, slab_off(split, i, t));
+        const uint32_t before = xwg_arrive(st, bcast, tid);
+        if (before == (uint32_t)(nsl - 1)) {
+            f32x4_t s[4][NT2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) s[i][t] = xwg_load(slab, slab_off(0, i, t));
+            for (int s2 = 1; s2 < nsl; ++s2) {
+                f32x4_t ld[4][NT2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) ld[i][t] = xwg_load(slab, slab_off(s2, i, t));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) s[i][t] += ld[i][t];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) store_d(i, t, s[i][t]);
+            xwg_reset(st, tid);
+        }
+    }
+}
+
+}  // namespace flute_amd

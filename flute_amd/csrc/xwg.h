@@ -1,0 +1,121 @@
+// Cross-workgroup reduction of split-K partial tiles INSIDE one launch (round 4).
+//
+// gfx950 counterpart of the reference's Stream-K fix-up (flute/csrc/tile_scheduler_utils.hpp:58-211: FixupHelper -
+// partial accumulators in the workspace, flag barriers, the workspace left clean for the next call, :196).  Until
+// round 3 a grid-level K split here meant fp32 slabs + a SECOND launch (>= 2 us of kernel boundary, the slabs dirty in
+// L2 behind it); the one in-launch attempt used agent-scope release fences (an L2 write-back per workgroup on this
+// 8-die part: 51 us at four splits).  This header is the cheap form MI355X_MICROARCH.md prices (rows handoff-flag,
+// publish-large, splitk-seam):
+//   * partial tiles are stored WRITE-THROUGH (`buffer_store_dwordx4 ... sc1`): no release fence, no L2 write-back;
+//   * every storing wave drains its own stores (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane
+//     arrives with a relaxed agent-scope atomic on the tile's state word;
+//   * whoever combines reads the other slices' partials with `sc1` loads (they bypass the reader's L1; the lines were
+//     never left in the writers' L2) - no acquire fence;
+//   * nothing depends on dispatch order or on where a workgroup runs, and nobody ever waits for a workgroup that has not
+//     ARRIVED (arrived = running): the bounded poll below may give up, it cannot deadlock;
+//   * the state words are zero again when the launch ends (the last arriver resets them): a hipGraph replays the launch
+//     without a memset node, the caller's zero-filled workspace (flute/utils.py:36-45) stays clean.
+//
+// Two forms, chosen by the kernel:
+//   L ("last arriver combines"): every slice publishes its whole partial tile; the workgroup whose arrival completes the
+//     count adds the others to its registers and writes D.  For small tiles (M <= 16 slabs: 4 KB per slice).
+//   E ("every slice combines its share"): the tile is cut into `nsh` = splitk shares, slice s owns share s, publishes
+//     the OTHER shares only, waits (bounded) until all slices have arrived, claims its share, adds the others' partials
+//     of it to its own registers and writes that part of D.  A slice whose wait runs out publishes its own share too and
+//     marks it abandoned; the last arriver - which by construction finds every partial in place - combines abandoned
+//     shares after its own.  For large tiles (128 x 128 fp32 = 64 KB per slice: one round trip of 48 KB per workgroup
+//     instead of 192 KB through the last arriver).
+//
+// State per output tile, two words in the FIRST kXwgFlagBytes of the caller's workspace (the slabs start behind them):
+//   w0: arrivals;   w1: bit q = share q claimed by its owner, bit 16 + q = share q abandoned (published in full).
+#pragma once
+#include "common.h"
+
+namespace flute_amd {
+
+constexpr size_t kXwgFlagBytes = 64 * 1024;
+constexpr int kXwgMaxTiles = (int)(kXwgFlagBytes / 8);
+constexpr unsigned kXwgSpinLimit = 4096;          // polls of ~0.3-1 us each before an owner gives its share up
+
+typedef uint32_t xwg_u32x4 __attribute__((ext_vector_type(4)));
+// state words are addressed as GLOBAL memory (global_atomic_*, not flat_*: MI355X_MICROARCH.md, Guideline 16)
+typedef __attribute__((address_space(1))) uint32_t xwg_word;
+__device__ __forceinline__ xwg_word* xwg_state(uint32_t* p) { return (xwg_word*)p; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xwg_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// 16-B write-through store / L1-bypassing load at byte offset `off` of the slab region (aux 16 = sc1)
+__device__ __forceinline__ void xwg_store(f32x4_t v, __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xwg_u32x4, v), r, (int)off, 0, 16);
+}
+__device__ __forceinline__ f32x4_t xwg_load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16));
+}
+
+// Publish point.  EVERY wave of the workgroup calls this after its last partial store: drains the wave's stores, meets
+// the others, lane 0 of the workgroup arrives; returns the number of slices that had arrived before (wave-uniform).
+// `bcast` = a free LDS dword (byte address): the barrier inside also retires every earlier LDS use of the workgroup.
+__device__ __forceinline__ uint32_t xwg_arrive(xwg_word* st, uint32_t bcast, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)bcast = before;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(lds_ld32(bcast));
+}
+
+// E form, an owner that was not last: one lane polls the arrival count (relaxed, with s_sleep); the other waves park at
+// the barrier.  Returns 1 when all `nsl` slices have arrived, 0 when the poll ran out.
+__device__ __forceinline__ uint32_t xwg_wait_all(xwg_word* st, uint32_t nsl, uint32_t bcast, int tid) {
+    if (tid == 0) {
+        uint32_t ok = 0;
+        for (unsigned spin = 0; spin < kXwgSpinLimit; ++spin) {
+            if ((__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) >= nsl) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)bcast = ok;
+    }
+    __syncthreads();
+    const uint32_t ok = __builtin_amdgcn_readfirstlane(lds_ld32(bcast));
+    __syncthreads();                              // `bcast` may be reused
+    return ok;
+}
+__device__ __forceinline__ void xwg_claim(xwg_word* st, uint32_t share, int tid) {
+    if (tid == 0) (void)__hip_atomic_fetch_or(st + 1, 1u << share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// after the abandoned share's own partial has been stored by every wave
+__device__ __forceinline__ void xwg_abandon(xwg_word* st, uint32_t share, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) (void)__hip_atomic_fetch_or(st + 1, 0x10000u << share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// E form, the last arriver after its own share: waits until every other share is claimed or abandoned (their owners
+// have all arrived, i.e. are running a bounded poll: this terminates) and returns the abandoned set (bit q).
+__device__ __forceinline__ uint32_t xwg_sweep(xwg_word* st, uint32_t nsl, uint32_t mine, uint32_t bcast, int tid) {
+    if (tid == 0) {
+        const uint32_t want = ((1u << nsl) - 1u) & ~(1u << mine);
+        uint32_t w1 = 0;
+        for (unsigned spin = 0; spin < (kXwgSpinLimit << 4); ++spin) {   // (a bound for form's sake: every owner's poll is bounded)
+            w1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((((w1 | (w1 >> 16)) & want) == want)) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)bcast = (w1 >> 16) & want;
+    }
+    __syncthreads();
+    const uint32_t ab = __builtin_amdgcn_readfirstlane(lds_ld32(bcast));
+    __syncthreads();
+    return ab;
+}
+// the last arriver, when nobody can touch the tile's state any more: leave it clean for the next launch
+__device__ __forceinline__ void xwg_reset(xwg_word* st, int tid) {
+    if (tid == 0) {
+        __hip_atomic_store(st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace flute_amd

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FLUTE_AMD_ABI_VERSION 4
+#define FLUTE_AMD_ABI_VERSION 5
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -69,7 +69,9 @@ typedef struct flute_plan {
                             LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
                             (4-bit, enough 128/256 x 256 output blocks to fill the chip), 5 = skinny MFMA kernel
                             (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
-                            slabs fill 55..100 % of the CUs; weights and activations straight to registers) */
+                            slabs fill 55..100 % of the CUs; weights and activations straight to registers),
+                            6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, 128 x 128 output tiles x splitk K
+                            slices, one workgroup each, partial tiles combined inside the launch) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
@@ -90,11 +92,14 @@ typedef struct flute_plan {
                             wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
                             (qgemm_persist.h: table / activations staged once, every wave walks `visits` units of
                             `k_chunks` segments of ring_depth pieces, the next segment requested ahead) */
+    int splitk_mode;     /* splitk > 1: 0 = fp32 slabs in the workspace + a second (reduce) launch, 1 = combined inside the
+                            launch (csrc/xwg.h: write-through slabs + one arrival word per output tile) */
 } flute_plan;
 
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
  *   family          5 skinny MFMA kernel (4-bit, M <= 16; waves 4 / 8 picks the in-workgroup K split);
+ *                   6 split-K block kernel (splitk picks the K slices per 128 x 128 tile; 1 = none);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
  *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)

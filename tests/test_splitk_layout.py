@@ -1,0 +1,120 @@
+"""Layout contracts of the split-K block kernel (flute_amd/csrc/qgemm_splitk.h), modelled lane by lane on the CPU: what a
+wave's LDS-DMA requests write, what its ds_read_b128 / ds_read_u16 then read, which bank slots the reads of a lane group
+touch, and the plan the host makes for it.  The formulas below are the kernel's, transcribed; the GPU parity tests
+(tests/test_qgemm_gpu.py::test_splitk_block_kernel) check the kernel itself against the oracle."""
+import numpy as np
+import pytest
+
+from flute_amd import _lib
+
+# ds_read_b128 lane groups of MI355X_MICROARCH.md (LDS table): one LDS cycle per group when the 16 lanes hit 16 different
+# 16-B slots of the 256-B bank row
+GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+GROUPS += [[l + 32 for l in g] for g in GROUPS]
+
+
+def sk_swz(row8, rh):
+    return (row8 >> 1) | (rh << 2)
+
+
+def test_activation_pieces_land_where_the_fragments_read_them():
+    K, m0, k0 = 256, 128, 64
+    X = np.arange(384 * K, dtype=np.int64).reshape(384, K)          # value = flat element index
+    stage = np.full(16 * 1024 // 2, -1, dtype=np.int64)               # one 64-k stage of a K half, in 2-B elements
+    for wg in range(4):                                               # the four waves of a K half, PPW = 4 pieces each
+        for i in range(4):
+            rt, rh = wg * 2 + (i >> 1), i & 1
+            for lane in range(64):
+                row8 = lane >> 3
+                src_row = m0 + rt * 16 + rh * 8 + row8
+                src_k = k0 + ((lane & 7) ^ sk_swz(row8, rh)) * 8
+                dst = ((wg * 4 + i) * 1024 + lane * 16) // 2          # lane-linear 16 B
+                stage[dst:dst + 8] = X[src_row, src_k:src_k + 8]
+    assert (stage >= 0).all()
+    for R in range(8):
+        for h in range(2):
+            addrs = {}
+            for lane in range(64):
+                r16, q4 = lane & 15, lane >> 4
+                a = R * 2048 + (r16 >> 3) * 1024 + (r16 & 7) * 128 + (((h * 4 + q4) ^ sk_swz(r16 & 7, r16 >> 3)) * 16)
+                addrs[lane] = a
+                got = stage[a // 2:a // 2 + 8]
+                want = X[m0 + R * 16 + r16, k0 + h * 32 + q4 * 8:k0 + h * 32 + q4 * 8 + 8]   # MFMA B operand: row r16, k = 8 q4 ..
+                assert (got == want).all(), (R, h, lane)
+            for grp in GROUPS:
+                assert len({(addrs[l] // 16) % 16 for l in grp}) == 16, (R, h)
+
+
+@pytest.mark.parametrize("bits,tile_p", [(4, 32), (4, 64), (2, 32), (2, 64)])
+def test_scale_image_and_output_columns(bits, tile_p):
+    J = 16 // bits
+    U = 32 // J
+    FPT = 16 // U
+    N, G, lg = 512, 40, 6
+    S = np.arange(N * G, dtype=np.int64).reshape(N, G)
+
+    def unit_col0(u):
+        return (u // tile_p) * (J * tile_p) + (u % tile_p)
+
+    for unit0 in (0, U * 5):
+        for kbeg in (0, 512, 1600):                                   # first group 0, 8, 25
+            g0e = (kbeg >> lg) & ~7
+            img = np.full(2048 // 2, -1, dtype=np.int64)
+            for r in range(2):
+                for lane in range(64):
+                    cl = lane & 31
+                    col = unit_col0(unit0 + cl % U) + (cl // U) * tile_p
+                    g = g0e + (lane >> 5) * 8 + r * 16
+                    dst = (r * 1024 + lane * 16) // 2
+                    for e in range(8):
+                        img[dst + e] = S[col, g + e] if g + e < G else 0
+            for lane in range(64):
+                r16 = lane & 15
+                u8, fsel = r16 % U, r16 // U
+                for t in range(2):
+                    col = unit_col0(unit0 + u8) + (fsel + FPT * t) * tile_p    # weight row r16 of column tile t
+                    for k in range(kbeg, min(kbeg + 1024, G << lg), 32):
+                        rel = (k >> lg) - g0e
+                        if rel >= 32:
+                            break
+                        a = (fsel * U + u8) * 16 + (rel >> 3) * 512 + (rel & 7) * 2 + t * 256
+                        assert img[a // 2] == S[col, k >> lg], (lane, t, k)
+    # the epilogue's four consecutive columns: accumulator register j of lane (r16, q4) = weight row 4 q4 + j
+    for q4 in range(4):
+        c_unit = (4 * q4) % U
+        for t in range(2):
+            c0 = unit_col0(c_unit) + ((4 * q4) // U + FPT * t) * tile_p
+            for j in range(4):
+                rho = 4 * q4 + j
+                assert unit_col0(rho % U) + (rho // U + FPT * t) * tile_p == c0 + j
+
+
+def _plan(M, N, K, bits=4, g=64, tid=16, ws=64 << 20, dtype=0, **ovr):
+    p = _lib.Plan()
+    rc = _lib.get().flute_qgemm_plan_ex(dtype, bits, g, M, N, K, tid, 256, ws, _lib.Overrides(**ovr), p)
+    return rc, p
+
+
+def test_plan_family6():
+    rc, p = _plan(256, 4096, 4096, family=6)
+    assert rc == 0 and p.family == 6 and p.block == 512 and p.waves == 8 and p.kw == 2
+    assert p.splitk == 4 and p.k_per_split == 1024 and p.grid == 256 and p.splitk_mode == 1
+    assert p.workspace_needed == 4 * 256 * 4096 * 4 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384
+    assert _plan(256, 4096, 4096, family=6, splitk=16)[0] != 0         # 64 MiB of slabs + the state words: one page too many
+    for sk in (1, 2, 4, 8, 16):
+        rc, p = _plan(256, 4096, 4096, family=6, splitk=sk, ws=128 << 20)
+        assert rc == 0 and p.splitk == sk and p.grid == 64 * sk and p.k_per_split * sk == 4096
+        assert p.splitk_mode == (1 if sk > 1 else 0)
+    assert _plan(256, 4096, 4096, family=6, splitk=3)[0] != 0          # 4096 / 3
+    assert _plan(256, 4096, 4096, family=6, splitk=32)[0] != 0
+    assert _plan(256, 4096, 4096, family=6, splitk=4, ws=1 << 20)[0] != 0   # slabs do not fit
+    assert _plan(256, 4096, 4096, family=6, splitk=1, ws=0)[0] == 0
+    assert _plan(256, 4096, 4096, bits=3, tid=0, family=6)[0] != 0     # 3 bits: other kernels
+    assert _plan(256, 4096, 4096, g=32, family=6, splitk=1)[0] != 0    # 64 groups per K half: more than four scale blocks
+    assert _plan(256, 4096, 4096, g=32, family=6, splitk=2)[0] == 0
+    rc, p = _plan(256, 4096, 4096, g=256, family=6, splitk=8)           # K half = one 256-wide group
+    assert rc == 0 and p.k_per_split == 512
+    assert _plan(256, 4096, 4096, g=256, family=6, splitk=16)[0] != 0
+    rc, p = _plan(200, 11008, 4096, family=6)
+    assert rc == 0 and p.grid == 2 * 86 * p.splitk
+    assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=7)[0] != 0   # unknown families are refused
