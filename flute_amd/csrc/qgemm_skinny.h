@@ -34,11 +34,12 @@
 #pragma once
 #include "qgemm_oneshot.h"
 #include "mfma.h"
+#include "xwg.h"
 
 namespace flute_amd {
 
 struct SkinnyGeo {
-    static constexpr uint32_t pack(int lg, int lkw, int ipw) { return (uint32_t)lg | ((uint32_t)lkw << 4) | ((uint32_t)ipw << 20); }
+    static constexpr uint32_t pack(int lg, int lkw, int ipw, int splitk = 1) { return (uint32_t)lg | ((uint32_t)lkw << 4) | ((uint32_t)splitk << 8) | ((uint32_t)ipw << 20); }
 };
 __host__ __device__ constexpr size_t skinny_lds_bytes(int bits, int mt, int kw) {
     const int J = 16 / bits;
@@ -50,7 +51,8 @@ __host__ __device__ constexpr size_t skinny_lds_bytes(int bits, int mt, int kw) 
 template <typename T, int BITS, int TILEP, int MT, int D, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
-    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp, uint64_t* __restrict__ stamps) {
+    const uint32_t* __restrict__ QM2, int K, int N, uint32_t geo, int M, void* __restrict__ Dp, uint64_t* __restrict__ stamps,
+    float* __restrict__ partial, uint32_t* __restrict__ state) {
     static_assert(BITS == 4, "2- and 3-bit layers take the per-wave kernel");
     using NT = Num<T>;
     constexpr int J = 16 / BITS;                                   // column tiles per k-step
@@ -80,11 +82,15 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     const int u = lane & 15, q = lane >> 4;
     const int units = N >> LJ;
     const int slabs = units >> 4;
-    const int slab = (int)blockIdx.x;
+    // grid-level K split (round 4): workgroup = (slab, K slice), the slices of a slab are neighbours in the block order and
+    // meet through the workspace (xwg.h, L form: 4 KB per slice at M = 16); nsplit = 1: the whole of K, as before
+    const int nsplit = (geo >> 8) & 255;
+    const int slab = nsplit > 1 ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
+    const int split = nsplit > 1 ? (int)blockIdx.x % nsplit : 0;
     const int G = K >> lg;
-    const int ksteps = K >> 5;
-    const int kp = wave;                                           // this wave's K part: k-steps [kp D, kp D + D)
-    const bool active = kp * D < ksteps;                           // K % (32 D) == 0: a part is whole or empty
+    const int ksteps = (K >> 5) / nsplit;                          // k-steps of this workgroup's slice (K % (32 nsplit) == 0)
+    const int kp = split * (ksteps / D) + wave;                    // this wave's K part: k-steps [kp D, kp D + D) of the row (ksteps % D == 0)
+    const bool active = wave * D < ksteps;                         // a part is whole or empty
     const uint32_t row_bytes = (uint32_t)K * 2u;
     const uint32_t kbyte0 = (uint32_t)(kp * D) * 64u + (uint32_t)q * 16u;      // this lane's 16 B of k-step 0 inside a row
     const uint32_t dead = 0x80000000u;
@@ -301,13 +307,54 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             *reinterpret_cast<ushort4*>(Dout + (size_t)row * N + col) = o;
         }
     };
-    for (int e = wave; e < NI; e += KW) {
-        float4 s = red[e * 64 + lane];
-        for (int ww = 1; ww < KW; ++ww) {
-            const float4 p = red[(ww * NI + e) * 64 + lane];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    if (nsplit == 1) {
+        for (int e = wave; e < NI; e += KW) {
+            float4 s = red[e * 64 + lane];
+            for (int ww = 1; ww < KW; ++ww) {
+                const float4 p = red[(ww * NI + e) * 64 + lane];
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+            store_tile(e, s);
         }
-        store_tile(e, s);
+    } else {
+        // the slice's partial tiles go to its fp32 slab write-through; the workgroup whose arrival completes the slab's count
+        // sums ALL slices in ascending order (its own from the slab too: the result does not depend on who is last)
+        const __amdgpu_buffer_rsrc_t slabs = xwg_rsrc(partial, (uint32_t)((size_t)nsplit * M * N * 4));
+        const uint32_t slice_bytes = (uint32_t)((size_t)M * N * 4);
+        auto tile_off = [&](int e) {
+            const int t = e / MT, mt = e % MT;
+            const int row = mt * 16 + u;
+            const int col = unit_col0<BITS, TILEP>(slab * 16 + 4 * q) + t * TILEP;
+            return row < M ? (uint32_t)(((size_t)row * N + col) * 4) : 0xfffffff0u;
+        };
+        for (int e = wave; e < NI; e += KW) {
+            float4 s = red[e * 64 + lane];
+            for (int ww = 1; ww < KW; ++ww) {
+                const float4 p = red[(ww * NI + e) * 64 + lane];
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+            const uint32_t off = tile_off(e);
+            if (off != 0xfffffff0u) xwg_store(f32x4_t{s.x, s.y, s.z, s.w}, slabs, (uint32_t)split * slice_bytes + off);
+        }
+        xwg_word* st = xwg_state(state + 2 * slab);
+        const uint32_t before = xwg_arrive(st, (uint32_t)red_off, tid);
+        if (before == (uint32_t)(nsplit - 1)) {
+            for (int e = wave; e < NI; e += KW) {
+                const uint32_t off = tile_off(e);
+                f32x4_t acc4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (off != 0xfffffff0u) {
+                    for (int s0 = 0; s0 < nsplit; s0 += 4) {       // four slices in flight
+                        f32x4_t ld[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ld[j] = xwg_load(slabs, s0 + j < nsplit ? (uint32_t)(s0 + j) * slice_bytes + off : 0xfffffff0u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc4 += ld[j];    // past the last slice: out of range reads as zero
+                    }
+                }
+                store_tile(e, make_float4(acc4[0], acc4[1], acc4[2], acc4[3]));
+            }
+            xwg_reset(st, tid);
+        }
     }
 #ifdef FLUTE_STAMPS
     FLUTE_KSTAMP(10);

@@ -81,6 +81,18 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();
+#ifdef FLUTE_STAMPS   // development build (tools/stamps_splitk.py): 100 MHz wall-clock stamps per wave behind the slabs
+    uint64_t stamp[12];
+    for (int i = 0; i < 12; ++i) stamp[i] = 0;
+    stamp[0] = wall_clock64();
+#define FLUTE_SKSTAMP(i) stamp[i] = wall_clock64()
+#define FLUTE_SKSTAMP_FLUSH() do { __builtin_amdgcn_s_waitcnt(0); stamp[8] = wall_clock64(); \
+        if ((threadIdx.x & 63) == 0) { uint64_t* o = reinterpret_cast<uint64_t*>(a.partial + (size_t)a.splitk * a.M * a.N) + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 12; \
+            for (int i = 0; i < 12; ++i) o[i] = stamp[i]; } } while (0)
+#else
+#define FLUTE_SKSTAMP(i)
+#define FLUTE_SKSTAMP_FLUSH()
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(BATCH) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    FLUTE_SKSTAMP(1);
     scales(0, 0);
     {
         const u32x4_t qw = w[0][0];
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     wait_lds();                                                    // the prefetch past the end
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
 
+    FLUTE_SKSTAMP(2);
     // ---- epilogue 1: the K halves swap half of their row tiles through LDS (K half 0 keeps row tiles 0..3, K half 1
     // keeps 4..7); own[i][t] = row tile 4 kh + i over the workgroup's whole K range ----
     f32x4_t own[4][NT2];
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         }
     }
 
+    FLUTE_SKSTAMP(3);
     // ---- epilogue 2: accumulator register j of lane (r16, q4) = weight row 4 q4 + j of the column tile = unit
     // (4 q4 + j) % U, field (4 q4) / U + FPT t: four consecutive columns; the lane's output row is r16 ----
     const int c_unit = unit0 + (4 * q4) % U;
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) store_d(i, t, own[i][t]);
+        FLUTE_SKSTAMP_FLUSH();
         return;
     }
 
@@ -372,11 +388,18 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
                     f32x4_t s = first[jj][t];
 #pragma unroll
                     for (int o = 0; o < NSH - 1; ++o) s += ld[jj][t][o];
+                    FLUTE_SKSTAMP(7);
                     store_d(sh + jj * NSH, t, s);
                 }
         };
+        FLUTE_SKSTAMP(4);
         const uint32_t before = xwg_arrive(st, bcast, tid);
+        FLUTE_SKSTAMP(5);
+#ifdef FLUTE_STAMPS
+        stamp[9] = before;
+#endif
         if (before == (uint32_t)(NSH - 1)) {
+            FLUTE_SKSTAMP(6);
             combine(me, mine);
             const uint32_t ab = xwg_sweep(st, NSH, me, bcast, tid);
             for (int q = 0; q < NSH; ++q) {
@@ -390,6 +413,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
             }
             xwg_reset(st, tid);
         } else if (xwg_wait_all(st, NSH, bcast, tid)) {
+            FLUTE_SKSTAMP(6);
             xwg_claim(st, me, tid);
             combine(me, mine);
         } else {
@@ -412,7 +436,12 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) xwg_store(own[i][t], slab, slab_off(split, i, t));
+        FLUTE_SKSTAMP(4);
         const uint32_t before = xwg_arrive(st, bcast, tid);
+        FLUTE_SKSTAMP(5);
+#ifdef FLUTE_STAMPS
+        stamp[9] = before;
+#endif
         if (before == (uint32_t)(nsl - 1)) {
             f32x4_t s[4][NT2];
 #pragma unroll
@@ -437,6 +466,9 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
             xwg_reset(st, tid);
         }
     }
+    FLUTE_SKSTAMP_FLUSH();
+#undef FLUTE_SKSTAMP
+#undef FLUTE_SKSTAMP_FLUSH
 }
 
 }  // namespace flute_amd
