@@ -282,13 +282,21 @@ int plan_persist(int bits, int lg, int M, int N, int K, int num_sms, const flute
 }
 
 // Skinny MFMA kernel (qgemm_skinny.h): 4-bit, M <= 16.  A wave = one slab (16 units) x D k-steps, the 4 or 8 waves of a
-// workgroup share the slab's K (no grid-level split: see the kernel's header), so K = 32 D KW with D in {4, 8, 16}.
-int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, flute_plan* p, OneArgs* ka) {
+// workgroup share a K slice of the slab, so K = splitk x 32 D KW with D in {4, 8, 16}; splitk > 1 (round 4): the slices of a
+// slab are neighbouring workgroups and meet through the workspace inside the launch (xwg.h, L form).
+int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, size_t workspace_bytes, flute_plan* p, OneArgs* ka) {
     if (bits != 4 || M < 1 || M > 16 || lg < 5 || ((K >> lg) & 1) || K % 128) return FLUTE_ERR_SHAPE;
     const int units = N / 4;
     if (units % 16) return FLUTE_ERR_SHAPE;
     if ((size_t)units * K * 2 >= (size_t)0xfffffff0u || (size_t)(M + 16) * K * 2 >= (size_t)0x7ffffff0u) return FLUTE_ERR_SHAPE;
-    const int ksteps = K / 32;
+    const int sk = ov.splitk > 1 ? ov.splitk : 1;
+    if (sk > 1) {
+        // slabs: 4 KB (four 16 x 16 fp32 tiles in fragment order) per slab and slice
+        if (sk > 16 || (K / 32) % sk || units / 16 > kXwgMaxTiles || (size_t)sk * (units / 16) * 4096 > slab_room(workspace_bytes) ||
+            (size_t)sk * (units / 16) * 4096 >= ((size_t)1 << 31))
+            return FLUTE_ERR_SHAPE;
+    }
+    const int ksteps = K / 32 / sk;
     int KW = 0, D = 0;
     for (int kw : {8, 4}) {
         if (ov.waves > 0 && kw != ov.waves) continue;
@@ -300,11 +308,12 @@ int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, flute_plan
     }
     if (!KW) return FLUTE_ERR_SHAPE;
     p->family = kFamilySkinny;
-    p->m_block = 1; p->m_tiles = 1; p->slabs_per_wave = 1; p->waves = KW; p->kw = KW; p->splitk = 1;
-    p->k_per_split = K;
-    p->grid = (unsigned)(units / 16); p->block = (unsigned)(KW * 64);
+    p->m_block = 1; p->m_tiles = 1; p->slabs_per_wave = 1; p->waves = KW; p->kw = KW; p->splitk = sk;
+    p->k_per_split = K / sk;
+    p->grid = (unsigned)(units / 16 * sk); p->block = (unsigned)(KW * 64);
     p->lds_bytes = skinny_lds_bytes(4, 1, KW); p->lut_copies = 32; p->ring_depth = D; p->visits = 1; p->k_chunks = 1; p->one_shot = 0;
-    p->workspace_needed = 0;
+    p->splitk_mode = sk > 1 ? 1 : 0;
+    p->workspace_needed = sk > 1 ? (size_t)sk * (units / 16) * 4096 + kXwgFlagBytes : 0;
     if (ka) { memset(ka, 0, sizeof(*ka)); ka->lg = lg; ka->lkw = ilog2(KW); ka->ipw = ceil_div(oneshot_lut_runs(4), KW); ka->depth = D; }
     return FLUTE_OK;
 }
@@ -314,7 +323,8 @@ int plan_skinny(int bits, int lg, int M, int N, int K, const Ovr& ov, flute_plan
 // K / splitk a multiple of 2 x max(64, group) (two K halves per workgroup, each whole 64-k steps and whole groups), at
 // most four 8-group scale blocks per K half, slabs + state words inside the workspace.  Cost model (us, measured on
 // MI355X, profiles/r04/splitk_lab*.jsonl): rounds x (fixed + steps x per-step) + seam.
-int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& ov, size_t workspace_bytes, flute_plan* p) {
+int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& ov, size_t workspace_bytes, flute_plan* p,
+                int rank = 0, double* cost_us = nullptr) {
     if (bits != 2 && bits != 4) return FLUTE_ERR_SHAPE;
     const int g = 1 << lg, G = K >> lg;
     if (G % 8 || N % 128 || K % 128) return FLUTE_ERR_SHAPE;
@@ -326,26 +336,36 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         if (sk < 1 || sk > 16 || K % sk || (K / sk) % align) return false;
         const int gh = (K / sk / 2) >> lg;                     // groups per K half
         if (gh + ((gh % 8) ? 7 : 0) > 32) return false;
-        if (sk > 1 && ((size_t)sk * M * N * 4 > slab_room(workspace_bytes) || (size_t)sk * M * N * 4 >= ((size_t)1 << 31))) return false;
+        if (sk > 1 && ((size_t)sk * tiles * 65536 > slab_room(workspace_bytes) || (size_t)sk * tiles * 65536 >= ((size_t)1 << 31))) return false;   // slabs: 64 KB per tile and slice
         return true;
     };
+    // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run5*.jsonl): a round of workgroups costs ~9.5 us of
+    // launch, prologue, K-half exchange and stores + 0.85 .. 1.0 us per 64-k step (the more of the chip is busy the slower:
+    // 37.0 us on 64 CUs, 41.8 on 256 at K = 4096); the seam grows with the MB published write-through
+    // (E form at 2 slices ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
+    auto model_us = [&](int sk) {
+        const long wgs = tiles * sk;
+        const long rounds = (wgs + num_sms - 1) / num_sms;
+        const double fill = std::min(1.0, (double)wgs / num_sms);
+        const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
+        const double mb = sk == 1 ? 0.0 : (double)wgs * 0.065536 * ((sk == 2 || sk == 4) ? (sk - 1.0) / sk : 1.0);
+        const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : 1.5 + 0.5 * mb);
+        return rounds * (9.5 + steps * (0.85 + 0.15 * fill)) + seam;
+    };
     int best = 0;
+    double best_us = 0.0;
     if (ov.splitk > 0) {
         if (!legal(ov.splitk)) return FLUTE_ERR_SHAPE;
-        best = ov.splitk;
+        best = ov.splitk; best_us = model_us(best);
     } else {
-        double best_us = 1e30;
-        for (int sk = 1; sk <= 16; ++sk) {
-            if (!legal(sk)) continue;
-            const long wgs = tiles * sk;
-            const long rounds = (wgs + num_sms - 1) / num_sms;
-            const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
-            const double seam = sk == 1 ? 0.0 : ((sk == 2 || sk == 4) ? 3.5 : 3.0 + 1.0 * sk);
-            const double us = rounds * (2.5 + steps * 0.85) + seam;
-            if (us < best_us) { best_us = us; best = sk; }
-        }
-        if (!best) return FLUTE_ERR_SHAPE;
+        std::vector<std::pair<double, int>> c;
+        for (int sk = 1; sk <= 16; ++sk) if (legal(sk)) c.push_back({model_us(sk), sk});
+        if (c.empty()) return FLUTE_ERR_SHAPE;
+        std::sort(c.begin(), c.end());
+        const size_t pick = std::min((size_t)std::max(0, rank), c.size() - 1);
+        best = c[pick].second; best_us = c[pick].first;
     }
+    if (cost_us) *cost_us = best_us;
     memset(p, 0, sizeof(*p));
     p->family = kFamilySplitK;
     p->m_block = 0; p->m_tiles = 8; p->slabs_per_wave = 1; p->waves = 8; p->kw = 2;
@@ -353,7 +373,7 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     p->grid = (unsigned)(tiles * best); p->block = 512;
     p->lds_bytes = (size_t)splitk_lds_bytes(bits); p->lut_copies = 32;
     p->splitk_mode = best > 1 ? 1 : 0;
-    p->workspace_needed = best > 1 ? (size_t)best * M * N * 4 + kXwgFlagBytes : 0;
+    p->workspace_needed = best > 1 ? (size_t)best * tiles * 65536 + kXwgFlagBytes : 0;
     return FLUTE_OK;
 }
 
@@ -441,6 +461,9 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     return FLUTE_OK;
 }
 
+// ids whose last digit leaves the kernel choice to the planner: 4-bit QuantMapMode digit 0, every 2- / 3-bit id
+bool auto_digit_sk(int bits, int template_id) { return bits != 4 || (template_id % 4) == 0; }
+
 int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int template_id, int num_sms,
               size_t workspace_bytes, const Ovr& ov, flute_plan* p, flute_template_info* tinfo,
               StreamArgs* sa, OneArgs* oa) {
@@ -498,15 +521,24 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 &&
                            ((q4 == 0 && K >= 4096 && fill5) || q4 == 3);
         if (ov.family == kFamilySkinny || auto5) {
-            if (plan_skinny(bits, lg, M, N, K, ov, p, oa) == FLUTE_OK) return FLUTE_OK;
+            if (plan_skinny(bits, lg, M, N, K, ov, workspace_bytes, p, oa) == FLUTE_OK) return FLUTE_OK;
             memset(p, 0, sizeof(*p));
         }
     }
-    // Split-K block kernel (qgemm_splitk.h): by override (family 6)
+    // Split-K block kernel (qgemm_splitk.h): by override (family 6); by template - Stages 5 of the automatic digit at
+    // M >= 128 (SMs_Multiple 1 / 2 / 4: the cost model's best / second / third K split; those ids' old meaning, a quarter of
+    // the per-wave kernel's in-workgroup K split, is still reachable through digits 1 .. 3); automatically below, when
+    // its modelled time beats what the other MFMA kernels are modelled at
     if (ov.family == kFamilySplitK) {
         const int src = plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p);
         if (src == FLUTE_OK && p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
         return src;
+    }
+    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && M >= 128 && auto_digit_sk(bits, template_id);
+    if (sk_regime && t.stages == 5) {
+        if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p, t.sms_multiple == 1 ? 0 : (t.sms_multiple == 2 ? 1 : 2)) == FLUTE_OK)
+            return FLUTE_OK;
+        memset(p, 0, sizeof(*p));
     }
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
     // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks); scale rows in
@@ -516,6 +548,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
+    double alt_us = -1.0;                             // modelled time of the best other MFMA kernel (set by the block cost model)
     const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32, 3-bit: 16)
     const bool b3_ok = bits != 3 || (size_t)3 * (N >> 4) * K * 2 < (size_t)0xfffffff0u;   // one descriptor over Q
     const bool x32_ok = (size_t)(M + 256) * K * 2 < (size_t)0xfffffff0u;       // activation byte offsets are 32-bit voffsets
@@ -554,8 +587,30 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
             else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
+            alt_us = std::min(wave_us, std::min(t256, t128));
         }
         if (blk_cfg >= 0) family = kFamilyBlock;
+    }
+    // Split-K block kernel, automatic (the template's default Stages and SMs_Multiple): taken when its modelled time is
+    // 8 % under the best of the per-wave kernel (520 TFLOP/s at M = 256, - 55 at 128, + 55 per doubling) and the block kernels.
+    // Measured (tools/splitk_lab.py, us, automatic plan of round 3 -> this kernel): M = 256 x 4096 x 11008 44.5 -> 38.1,
+    // 4096 x 14336 47.2 -> 40.2, 8192^2 49.0 -> 44.2; M = 1024 x 4096^2 49.6 -> 41.8 (torch.mm 46.9), M = 512 29.0 -> 27.4;
+    // not taken: M = 256 x 4096^2 (24.9 against 20.1: the seam of four slices), M = 128 x 4096^2, K = 14336.
+    if (sk_regime && t.stages == 2 && t.sms_multiple == 1 && (blk_cfg < 0 || blk_cfg == 4 || blk_cfg == 5)) {
+        if (alt_us < 0.0) {
+            const bool bf = dtype == FLUTE_BF16;
+            int dbl = M < 256 ? -1 : 0;
+            for (int m = M; m >= 512; m >>= 1) ++dbl;
+            const double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            alt_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
+        }
+        flute_plan q;
+        double sk_us = 0.0;
+        if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, &q, 0, &sk_us) == FLUTE_OK && sk_us < 0.92 * alt_us &&
+            q.lds_bytes <= (size_t)kMaxLds) {
+            *p = q;
+            return FLUTE_OK;
+        }
     }
     p->family = family;
 
@@ -913,12 +968,15 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
         const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
-        uint32_t geo = SkinnyGeo::pack(oa.lg, oa.lkw, oa.ipw);
+        uint32_t geo = SkinnyGeo::pack(oa.lg, oa.lkw, oa.ipw, p.splitk);
         uint64_t* stamps = nullptr;
-#ifdef FLUTE_STAMPS
-        if (workspace && workspace_bytes >= (size_t)p.grid * p.waves * 128) stamps = reinterpret_cast<uint64_t*>(workspace);
+        float* partial = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes) : nullptr;
+        uint32_t* state = reinterpret_cast<uint32_t*>(workspace);
+#ifdef FLUTE_STAMPS   // behind the state words and the slabs
+        if (workspace && workspace_bytes >= p.workspace_needed + kXwgFlagBytes + (size_t)p.grid * p.waves * 128)
+            stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + (p.workspace_needed ? p.workspace_needed : kXwgFlagBytes));
 #endif
-        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D, &stamps};
+        void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D, &stamps, &partial, &state};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
             hipSuccess) {
             (void)hipGetLastError();

@@ -26,7 +26,7 @@ PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int ns
 PersistKernel persist_kernel_b2(int dtype, int tile_p, int mb, int depth, int nsets, int had);
 PersistKernel persist_kernel_b3(int dtype, int tile_p, int mb, int depth, int nsets, int had);
 // skinny MFMA kernel (qgemm_skinny.h): 4-bit, M <= 16, depth = k-steps per wave (4/8/16)
-typedef void (*SkinnyKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, uint64_t*);
+typedef void (*SkinnyKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, uint64_t*, float*, uint32_t*);
 SkinnyKernel skinny_kernel_b4(int dtype, int tile_p, int depth);
 // block-tiled prefill kernels (qgemm_block2.h / qgemm_block3.h): cfg 4 = 256 x 256 block, cfg 5 = 128 x 256, 8 + RT = skinny 3-bit blocks
 struct BlockArgs;

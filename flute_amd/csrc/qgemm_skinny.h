@@ -319,22 +319,17 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
     } else {
         // the slice's partial tiles go to its fp32 slab write-through; the workgroup whose arrival completes the slab's count
         // sums ALL slices in ascending order (its own from the slab too: the result does not depend on who is last)
-        const __amdgpu_buffer_rsrc_t slabs = xwg_rsrc(partial, (uint32_t)((size_t)nsplit * M * N * 4));
-        const uint32_t slice_bytes = (uint32_t)((size_t)M * N * 4);
-        auto tile_off = [&](int e) {
-            const int t = e / MT, mt = e % MT;
-            const int row = mt * 16 + u;
-            const int col = unit_col0<BITS, TILEP>(slab * 16 + 4 * q) + t * TILEP;
-            return row < M ? (uint32_t)(((size_t)row * N + col) * 4) : 0xfffffff0u;
-        };
+        // slabs in fragment order: [slice][slab][tile e][lane] x 16 B (one contiguous KB per store / load instruction)
+        const uint32_t slice_bytes = (uint32_t)slabs * (NI * 1024u);
+        const __amdgpu_buffer_rsrc_t slabr = xwg_rsrc(partial, (uint32_t)nsplit * slice_bytes);
+        auto tile_off = [&](int e) { return ((uint32_t)slab * NI + (uint32_t)e) * 1024u + (uint32_t)lane * 16u; };
         for (int e = wave; e < NI; e += KW) {
             float4 s = red[e * 64 + lane];
             for (int ww = 1; ww < KW; ++ww) {
                 const float4 p = red[(ww * NI + e) * 64 + lane];
                 s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
             }
-            const uint32_t off = tile_off(e);
-            if (off != 0xfffffff0u) xwg_store(f32x4_t{s.x, s.y, s.z, s.w}, slabs, (uint32_t)split * slice_bytes + off);
+            xwg_store(f32x4_t{s.x, s.y, s.z, s.w}, slabr, (uint32_t)split * slice_bytes + tile_off(e));
         }
         xwg_word* st = xwg_state(state + 2 * slab);
         const uint32_t before = xwg_arrive(st, (uint32_t)red_off, tid);
@@ -342,14 +337,12 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             for (int e = wave; e < NI; e += KW) {
                 const uint32_t off = tile_off(e);
                 f32x4_t acc4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (off != 0xfffffff0u) {
-                    for (int s0 = 0; s0 < nsplit; s0 += 4) {       // four slices in flight
-                        f32x4_t ld[4];
+                for (int s0 = 0; s0 < nsplit; s0 += 4) {           // four slices in flight
+                    f32x4_t ld[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) ld[j] = xwg_load(slabs, s0 + j < nsplit ? (uint32_t)(s0 + j) * slice_bytes + off : 0xfffffff0u);
+                    for (int j = 0; j < 4; ++j) ld[j] = xwg_load(slabr, s0 + j < nsplit ? (uint32_t)(s0 + j) * slice_bytes + off : 0xfffffff0u);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc4 += ld[j];    // past the last slice: out of range reads as zero
-                    }
+                    for (int j = 0; j < 4; ++j) acc4 += ld[j];        // past the last slice: out of range reads as zero
                 }
                 store_tile(e, make_float4(acc4[0], acc4[1], acc4[2], acc4[3]));
             }

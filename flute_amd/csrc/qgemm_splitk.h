@@ -22,7 +22,7 @@
 // ascending; L: all slices ascending), so the result does not depend on arrival order.
 // Arithmetic contract as qgemm_block2.h: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation, one rounding.
 // Host contract (api.hip, plan_splitk): 2 or 4 bits, G % 8 == 0, K % k_per_split == 0, k_per_split % (2 * max(64, g)) == 0,
-// at most 32 scale groups (+ alignment slack: four 8-group blocks) per K half, splitk * M * N * 4 < 2^31.
+// at most 32 scale groups (+ alignment slack: four 8-group blocks) per K half, splitk * tiles * 64 KB of slabs < 2^31.
 #pragma once
 #include <utility>
 
@@ -37,7 +37,7 @@ struct SplitKArgs {
     void* D;                // [M,N] T
     const void* S;          // [N,G] T
     const uint32_t* QM2;    // [4^b] pair table
-    float* partial;         // [splitk][M][N] fp32 slabs (write-through), splitk > 1
+    float* partial;         // [splitk][tile] x 64 KB fp32 partial tiles in fragment order (write-through), splitk > 1
     uint32_t* state;        // two words per output tile, zero before and after the launch (xwg.h)
     int M, N, K, G, lg;
     int tiles_m;            // 128-row tiles (fastest in the block order: the row tiles of a column tile are neighbours)
@@ -65,7 +65,15 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     constexpr int FB = 2 * BITS;
     constexpr int RT = SK_RT, NT2 = 2, NWN = 4;
     constexpr int PPW = RT * 2 / NWN;                              // activation pieces per wave and step (4)
-    constexpr int BATCH = PPW + 2;                                 // + two weight pieces
+#ifdef FLUTE_SK_ABLATE   // development builds (tools/splitk_ablate.sh): 1 no activation requests in the loop, 2 no weight requests,
+    constexpr int dbg = FLUTE_SK_ABLATE;                           // 4 no MFMA, 8 no table lookups, 16 no fragment reads, 32 no barriers
+#else
+    constexpr int dbg = 0;
+#endif
+    // A step's batch: 4 activation pieces + 2 weight pieces.  (Measured and dropped, profiles/r04/splitk_lab_run4_line_touch_
+    // prefetch_dropped.jsonl: one extra 4-B LDS-DMA per wave and step whose 64 lanes touch the 40 cache lines the wave will
+    // want eight steps later - the requests are priced per LINE, so it doubled the addresser's work: 24.5 -> 27.8 us.)
+    constexpr int BATCH = ((dbg & 1) ? 0 : PPW) + ((dbg & 2) ? 0 : 2);
     static_assert(BATCH <= RT, "one request per row tile of half step 0");
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
     constexpr int X_BASE = LUT_BYTES;
@@ -143,12 +151,24 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         if constexpr (i < PPW) dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * SK_STAGE);
         else w[slot][i - PPW] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)(i - PPW) * 64u);
     };
+    // request j of a step's batch -> piece index (ablation builds drop the activation or the weight requests)
+    auto issue_nth = [&](auto slot_tag, auto j_tag, int u) {
+        constexpr int j = decltype(j_tag)::value;
+        issue_one(slot_tag, std::integral_constant<int, (dbg & 1) ? PPW + j : j>{}, u);
+    };
     auto issue_batch = [&](auto slot_tag, int u) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (issue_one(slot_tag, std::integral_constant<int, I>{}, u), ...);
-        }(std::make_integer_sequence<int, BATCH>{});
+        }(std::make_integer_sequence<int, PPW + 2>{});
     };
 
+    // ---- pair-table words first (oldest in the queue: their wait below leaves everything else in flight) ----
+    constexpr int ENT = 1 << (2 * BITS);
+    constexpr int LUT_R = (ENT * 8 + 511) / 512;                   // 16-B table pieces per thread
+    const srd_t lut_srd = make_srd(a.QM2, (uint32_t)(4 * ENT));
+    uint32_t lutw[LUT_R];
+#pragma unroll
+    for (int r = 0; r < LUT_R; ++r) lutw[r] = buf_load4((uint32_t)((tid + 512 * r) >> 3) * 4u, lut_srd);   // past the table: reads 0, not written
     // ---- scales of the whole K half, once: 8-group blocks from the block that holds the first group.  Request r, lane L:
     // block 2 r + L / 32 of column (unit L % U, field (L & 31) / U); image [block][column] x 16 B, lane-linear ----
     const int g0e = (kbeg >> a.lg) & ~7;
@@ -161,12 +181,13 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     }
     issue_batch(std::integral_constant<int, 0>{}, 0);
     issue_batch(std::integral_constant<int, 1>{}, 1);
-    {
-        constexpr int ENT = 1 << (2 * BITS);
-        for (int p = tid; p < ENT * 8; p += 512) {
-            const uint32_t v = a.QM2[p >> 3];
-            *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(v, v, v, v);
-        }
+    // the pair table (entry e: 32 copies of its word at [128 e, 128 e + 128)) is written while the scale blocks and the
+    // first two batches travel
+#pragma unroll
+    for (int r = 0; r < LUT_R; ++r) {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lutw[r]) : "n"(LUT_R - 1 - r + 2 + 2 * (PPW + 2)) : "memory");
+        const int p = tid + 512 * r;
+        if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lutw[r], lutw[r], lutw[r], lutw[r]);
     }
     const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
     // fragment of row tile R, half step h, stage slot: x_grp + slot * SK_STAGE + R * 2048 + piece (r16 >> 3) * 1024 + row
@@ -182,37 +203,49 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
 #pragma unroll
         for (int t = 0; t < NT2; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint32_t v[8];                                                 // hidden lookups of the NEXT half step: [tile][word]
-    u32x4_t af[RT];                                                // fragment slots (row tile R lives in slot R)
-    uint32_t scn[NT2];                                             // scales of the next half step
+    // Operands of a half step live in register set h (half step 0 of every K step: set 0, half step 1: set 1): while set h
+    // is multiplied, the LDS reads of the NEXT half step fill set h ^ 1 - all of them issued behind the first four row
+    // tiles' MFMAs, i.e. at least half a half step before they are needed (the first version reused ONE set in place: the
+    // last fragment / lookup of a half step was requested by its last row tile and the wave paid the LDS latency at every
+    // half-step boundary - 36 us instead of ~26 at K = 4096, profiles/r04/splitk_lab_run1*.jsonl)
+    uint32_t v[2][8];                                              // hidden lookups: [set][tile * 4 + word]
+    u32x4_t af[2][RT];                                             // activation fragments: [set][row tile]
+    uint32_t scn[2][NT2];                                          // scales: [set][column tile]
 
-    auto scales = [&](int t, int h) {
+    auto scales = [&](auto set_tag, int t, int h) {
+        constexpr int set = decltype(set_tag)::value;
         const int rel = ((kbeg + t * 64 + h * 32) >> a.lg) - g0e;
         const uint32_t sb = sc_lane + (uint32_t)(rel >> 3) * 512u + (uint32_t)(rel & 7) * 2u;
-        uint32_t& d0 = scn[0];
-        uint32_t& d1 = scn[1];
+        uint32_t& d0 = scn[set][0];
+        uint32_t& d1 = scn[set][1];
         asm volatile("ds_read_u16 %0, %1" : "=v"(d0) : "v"(sb) : "memory");
         asm volatile("ds_read_u16 %0, %1 offset:256" : "=v"(d1) : "v"(sb) : "memory");     // field + FPT = 16 image columns on
     };
-    auto lookup = [&](const u32x4_t& qw, auto n_tag) {
+    auto lookup = [&](auto set_tag, const u32x4_t& qw, auto n_tag) {
+        constexpr int set = decltype(set_tag)::value;
         constexpr int n = decltype(n_tag)::value;                  // tile n / 4, word n % 4
         const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(FB * FPT * (n >> 2)), (uint32_t)FB);
-        v[n] = lds_lookup32((idx << 7) | lane_off);
+        if constexpr (dbg & 8) v[set][n] = idx; else v[set][n] = lds_lookup32((idx << 7) | lane_off);
     };
-    auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
+    auto frag = [&](auto set_tag, auto slot_tag, auto h_tag, auto r_tag) {
+        constexpr int set = decltype(set_tag)::value;
         constexpr int R = decltype(r_tag)::value;
         constexpr int h = decltype(h_tag)::value;
         constexpr int off = decltype(slot_tag)::value * SK_STAGE + R * 2048;
         static_assert(off < 65536, "ds_read_b128 immediate offset");
-        u32x4_t& dst = af[R];
+        u32x4_t& dst = af[set][R];
         const uint32_t addr = h == 0 ? frag_b0 : frag_b1;          // (named outside the asm: a generic lambda captures no variable it only meets as an asm operand)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
     };
-    auto wait_lds = [&]() {
+    auto wait_lds = [&](auto set_tag) {                             // every LDS read issued so far has returned; names set `set`
+        constexpr int set = decltype(set_tag)::value;
+        uint32_t (&vv)[8] = v[set];                                // (references: a generic lambda captures no variable it only meets as an asm operand)
+        u32x4_t (&aa)[RT] = af[set];
+        uint32_t (&ss)[NT2] = scn[set];
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
-                       "+v"(scn[0]), "+v"(scn[1])
+                     : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]),
+                       "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(aa[4]), "+v"(aa[5]), "+v"(aa[6]), "+v"(aa[7]),
+                       "+v"(ss[0]), "+v"(ss[1])
                      : : "memory");
     };
 
@@ -221,32 +254,44 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         constexpr int h = decltype(h_tag)::value;
         constexpr int nslot = h ? (slot + 1) % BLK_STAGES : slot;
         constexpr int nh = h ^ 1;
-        wait_lds();
+        using cur_t = std::integral_constant<int, h>;
+        using nxt_t = std::integral_constant<int, nh>;
+        wait_lds(cur_t{});
         if constexpr (h == 0) {
-            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free: batch t+2 follows, spread over the rows
+            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();   // (A) stage t-1 is free: batch t+2 follows, spread over the rows
         } else {
             // (B) batch t+1 has landed once at most batch t+2 is outstanding
             asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
         }
         u32x4_t bf[NT2];
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
-            const uint32_t sj = scn[c];
+            const uint32_t sj = scn[h][c];
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], sj);
+            for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[h][c * 4 + ww], sj);
         }
-        scales(t + h, nh);
+        scales(nxt_t{}, t + h, nh);
         const u32x4_t qw = w[nslot][nh];
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
 #pragma unroll
-            for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R], acc[R][c]);
-            if constexpr (h == 0 && R < BATCH)
-                issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, r_tag, t + 2);
-            // the next half step's fragment of this row tile replaces the one just multiplied; one lookup rides along
-            frag(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{}, r_tag);
-            lookup(qw, r_tag);
+            for (int c = 0; c < NT2; ++c) {
+                if constexpr (dbg & 4) acc[R][c][0] += __builtin_bit_cast(float, bf[c][0] ^ af[h][R][0]);
+                else acc[R][c] = Mfma<T>::run(bf[c], af[h][R], acc[R][c]);
+            }
+            // the next half step's operands: two fragments and two lookups behind each of the first four row tiles
+            if constexpr (R < RT / 2) {
+                if constexpr (!(dbg & 16)) {
+                    frag(nxt_t{}, std::integral_constant<int, nslot>{}, nxt_t{}, std::integral_constant<int, 2 * R>{});
+                    frag(nxt_t{}, std::integral_constant<int, nslot>{}, nxt_t{}, std::integral_constant<int, 2 * R + 1>{});
+                }
+                lookup(nxt_t{}, qw, std::integral_constant<int, 2 * R>{});
+                lookup(nxt_t{}, qw, std::integral_constant<int, 2 * R + 1>{});
+            }
+            // batch t+2 behind the last BATCH row tiles of half step 0, one request each
+            if constexpr (h == 0 && R >= RT - BATCH)
+                issue_nth(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, R - (RT - BATCH)>{}, t + 2);
         };
         [&]<int... R>(std::integer_sequence<int, R...>) {
             (row(std::integral_constant<int, R>{}), ...);
@@ -254,18 +299,19 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     };
 
     // scales, batch 0 and the pair table before anyone reads them
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(BATCH) : "memory");
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(PPW + 2) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FLUTE_SKSTAMP(1);
-    scales(0, 0);
     {
+        using set0 = std::integral_constant<int, 0>;
+        scales(set0{}, 0, 0);
         const u32x4_t qw = w[0][0];
         [&]<int... R>(std::integer_sequence<int, R...>) {
-            (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
+            (frag(set0{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
         }(std::make_integer_sequence<int, RT>{});
         [&]<int... L>(std::integer_sequence<int, L...>) {
-            (lookup(qw, std::integral_constant<int, L>{}), ...);
+            (lookup(set0{}, qw, std::integral_constant<int, L>{}), ...);
         }(std::make_integer_sequence<int, 8>{});
     }
     auto step = [&](auto slot_tag, int t) {
@@ -280,7 +326,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         step(std::integral_constant<int, 2>{}, t0 + 2);
         if (t0 + 3 >= nsteps) break;
     }
-    wait_lds();                                                    // the prefetch past the end
+    wait_lds(std::integral_constant<int, 0>{});                    // the prefetch past the end (set 0: the last half step is a half step 1)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
 
     FLUTE_SKSTAMP(2);
@@ -343,12 +389,15 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         return;
     }
 
-    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(a.partial, (uint32_t)((size_t)a.splitk * a.M * a.N * 4));
-    const uint32_t slab_bytes = (uint32_t)((size_t)a.M * a.N * 4);
-    // byte offset of (slice, row tile i, column tile t) of this lane; rows past M: past the descriptor (stores dropped, loads 0)
+    // Slabs in FRAGMENT order: [slice][tile][wave][row tile i][column tile t][lane] x 16 B - every store / load instruction of
+    // a wave moves one contiguous KB, and the same lane of the same wave of another slice finds its counterpart at the same
+    // place (the reference's BlockStripedReduce does the same, tile_scheduler_utils.hpp:80-83).  The first version kept the
+    // slabs as [M][N] images: 32-B runs per row, write-through one fabric write each - 10 us of seam (profiles/r04).
+    const uint32_t ntiles = gridDim.x / (uint32_t)a.splitk;
+    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(a.partial, (uint32_t)a.splitk * ntiles * 65536u);
+    const uint32_t slab_lane = (uint32_t)tile * 65536u + (uint32_t)wave * 8192u + (uint32_t)lane * 16u;
     auto slab_off = [&](int slice, int i, int t) {
-        const int row = row_base + 16 * i;
-        return (row < a.M) ? (uint32_t)slice * slab_bytes + (uint32_t)(((size_t)row * a.N + col[t]) * 4) : 0xfffffff0u;
+        return (uint32_t)slice * (ntiles * 65536u) + slab_lane + (uint32_t)(i * NT2 + t) * 1024u;
     };
     xwg_word* st = xwg_state(a.state + 2 * tile);
     const uint32_t bcast = 0;                                      // LDS dword 0 (the pair table is dead)

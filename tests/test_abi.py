@@ -68,7 +68,12 @@ def test_plan_families_and_invariants():
                 want = 0                             # small 3-bit layers: the 4-row decode variant is faster than their MFMA plans
             if bits == 3 and M == 1000:
                 want = 3                             # 3 bits: the per-wave kernel is slow enough that 128 blocks already win
+            if bits != 3 and M == 1000:
+                want = 6                             # 2 / 4 bits: 8 x 32 tiles of 128 x 128, one per CU (qgemm_splitk.h, round 4)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
+            if p.family == 6:
+                assert (p.grid, p.block, p.splitk, p.workspace_needed) == (256, 512, 1, 0)
+                continue
             if p.family == 2:
                 assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)
             assert p.grid >= 1 and p.block % 64 == 0 and 64 <= p.block <= 1024
@@ -100,7 +105,15 @@ def test_plan_families_and_invariants():
     rc, p = plan(2048, 4096, 4096)
     assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 256      # 128-row blocks: one per CU
     rc, p = plan(1024, 4096, 4096)
-    assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel is faster
+    assert rc == 0 and p.family == 6 and p.grid == 256 and p.splitk == 1      # too few 128 / 256 x 256 blocks: 128 x 128 tiles (round 4; the per-wave kernel before)
+    rc, p = plan(256, 4096, 4096)
+    assert rc == 0 and p.family == 2                    # four K slices per tile would be needed: the seam costs more than it saves
+    rc, p = plan(256, 11008, 4096)
+    assert rc == 0 and p.family == 6 and (p.grid, p.splitk) == (172, 1)
+    rc, p = plan(256, 8192, 8192)
+    assert rc == 0 and p.family == 6 and (p.grid, p.splitk, p.splitk_mode) == (256, 2, 1) and p.workspace_needed == 2 * 128 * 65536 + 65536
+    rc, p = plan(256, 8192, 8192, ws=1 << 20)
+    assert rc == 0 and p.family != 6 or p.splitk == 1   # no room for the slabs: no in-launch split
     rc, p = plan(4096, 4096, 4096, bits=2, tid=0)
     assert rc == 0 and p.family == 3 and p.m_block == 4 and p.lds_bytes <= 160 * 1024      # 2-bit layers too
     rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
@@ -242,12 +255,19 @@ def test_plan_invariants_over_random_shapes():
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
             assert bits != 3 or p.m_block == 1, what
+        elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
+            tiles = -(-M // 128) * (N // 128)
+            assert bits in (2, 4) and M >= 128 and p.block == 512 and p.grid == tiles * p.splitk, what
+            assert p.k_per_split * p.splitk == K and p.k_per_split % (2 * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
+            gh = p.k_per_split // 2 // g
+            assert gh + (7 if gh % 8 else 0) <= 32, what
+            assert p.splitk_mode == (1 if p.splitk > 1 else 0) and p.workspace_needed == (p.splitk * tiles * 65536 + 65536 if p.splitk > 1 else 0), what
         else:                                                     # block kernels
             assert p.family == 3 and p.m_block in (4, 5, 9, 10, 12) and p.block == 512, what
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
             assert p.m_block != 4 or bits != 3 or p.lds_bytes == 146 * 1024, what
     # the sweep reaches every kernel of the library
-    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (2, 0), (3, 0), (5, 0)):
+    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (2, 0), (3, 0), (5, 0), (6, 0)):
         assert fams.get(key, 0) > 0, (key, fams)
 
 

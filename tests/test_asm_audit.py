@@ -41,6 +41,8 @@ def test_audit_rules_on_synthetic_streams(tmp_path):
     # LDS-DMA writes no VGPR: its first operand is the address and may be reused at once
     dma = "\t;;#ASMSTART\n\tbuffer_load_dwordx4 v3, s[4:7], s9 offen lds\n\t;;#ASMEND\n\tv_mov_b32_e32 v3, 0\n"
     assert _audit_text(tmp_path, dma) == []
+    gdma = "\t;;#ASMSTART\n\tglobal_load_lds_dword v[3:4], off\n\t;;#ASMEND\n\tv_mov_b32_e32 v3, 0\n"
+    assert _audit_text(tmp_path, gdma) == []
     # hidden LDS reads: in-order return, counted lgkmcnt
     lds = ("\t;;#ASMSTART\n\tds_read_b32 v30, v2\n\t;;#ASMEND\n\t;;#ASMSTART\n\tds_read_b32 v31, v2\n\t;;#ASMEND\n")
     lg1 = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(1)\n\t;;#ASMEND\n"

@@ -477,6 +477,145 @@ def test_block_prefill_kernel(env):
     assert dev.get_plan(700, 1024, 2048, 3, 64, 4, 256, torch.float16, dev.Overrides(family=3, m_tiles=8))["m_block"] == 4
 
 
+def _state_words_clean(env):
+    """First 64 KB of the workspace: the tile state words of the in-launch reductions (csrc/xwg.h) - zero between calls."""
+    return int(env.ws[:65536].view(torch.int32).abs().sum().item()) == 0
+
+
+def test_splitk_block_kernel(env):
+    """The split-K block kernel (family 6, qgemm_splitk.h): 128 x 128 tiles x K slices whose partial tiles meet inside the
+    launch (csrc/xwg.h - the role of the reference's FixupHelper, tile_scheduler_utils.hpp:58-211).  Every form of the seam
+    (no split; E form at 2 and 4 slices; L form at 3, 6, 8, 16), ragged M (rows past M read as zero, never stored), both
+    TileP layouts and dtypes, 2 and 4 bits, group sizes 32 .. 256 (the wave's scales for its whole K half are staged once);
+    against the oracle, one-hot rows bit-exact (w^ = round_T(lut * s)), repeated launches bit-identical (fixed summation
+    order) and the state words zero after every call (tile_scheduler_utils.hpp:196)."""
+    from flute_amd import dev
+    d = env.dev
+    assert _state_words_clean(env)
+    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, torch.float16, 4096, 1024), (4, 64, 64, torch.bfloat16, 2048, 1024),
+                                           (4, 32, 128, torch.float16, 3072, 512), (4, 32, 32, torch.bfloat16, 1024, 256),
+                                           (4, 64, 256, torch.float16, 4096, 256), (2, 32, 64, torch.float16, 2048, 1024),
+                                           (2, 64, 128, torch.bfloat16, 3072, 512), (2, 32, 32, torch.bfloat16, 1024, 256)]:
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K + N + 1)
+        What = env.O.dequantize(Q.numpy(), S, table2, bits, g, tile_p).float()
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for M in (1, 130, 256, 700):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            ref = X.float() @ What
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            ran = set()
+            for sk in (1, 2, 3, 4, 6, 8, 16):
+                ovr = dev.Overrides(family=6, splitk=sk)
+                try:
+                    plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
+                except RuntimeError:
+                    continue                                      # not a legal split of this K (qgemm_splitk.h's host contract)
+                assert plan["family"] == 6 and plan["splitk"] == sk and plan["grid"] == -(-M // 128) * (N // 128) * sk
+                ran.add(sk)
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                out2 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, sk)
+                assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk)
+                assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk)
+                assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk)
+            assert 1 in ran or g == 32 and K > 2048, (K, g, ran)
+            assert len(ran) >= 3, (K, g, ran)
+    # the planner takes it by itself where it was measured faster (profiles/r04): one workgroup per tile on the MLP widths
+    p = dev.get_plan(256, 11008, 4096, 4, 64, 16, 256, torch.float16)
+    assert p["family"] == 6 and (p["grid"], p["splitk"]) == (172, 1), p
+    p = dev.get_plan(1024, 4096, 4096, 4, 64, 16, 256, torch.bfloat16)
+    assert p["family"] == 6 and (p["grid"], p["splitk"]) == (256, 1), p
+    p = dev.get_plan(256, 8192, 8192, 4, 64, 16, 256, torch.float16)
+    assert p["family"] == 6 and (p["grid"], p["splitk"]) == (256, 2), p
+    assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2      # four slices: the seam costs more than it saves
+    # the automatic plan through the operator, at a BASELINE shape, against the per-wave kernel
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 4096, 11008
+    W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=11)
+    tid = template_ids_for(env.fa, bits, tile_p)[0]
+    X = (torch.randn(256, K) / 100).to(dtype)
+    a = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
+    b = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=2))
+    assert torch.equal(a, b) or rel_err(a, b.float()) < 2e-4         # same arithmetic contract, different summation order
+
+
+def test_splitk_seam_under_load(env):
+    """The in-launch reduction under uneven load: split-K launches of three weight sets back to back in one hipGraph (the
+    workgroups of neighbouring launches overlap at the seams, the slabs and state words are reused at once), replayed; every
+    result word for word what the first, isolated launch of that weight set produced (MI355X_MICROARCH.md: test every
+    hand-off under uneven load, consumer caches warm, every word)."""
+    import bench
+    from flute_amd import dev
+    for (M, N, K, sk, fam, dtype) in ((256, 4096, 4096, 4, 6, torch.float16), (200, 2048, 4096, 8, 6, torch.bfloat16),
+                                      (256, 2048, 8192, 2, 6, torch.float16), (16, 4096, 4096, 4, 5, torch.float16),
+                                      (9, 2048, 8192, 8, 5, torch.bfloat16)):
+        lay = bench.Layer(M, N, K, 4, 64, dtype, env.dev, 3)
+        lay.template_id = template_ids_for(env.fa, 4, 32)[0]
+        lay.ovr = dev.Overrides(family=fam, splitk=sk)
+        plan = dev.get_plan(M, N, K, 4, 64, lay.template_id, env.num_sms, dtype, lay.ovr)
+        assert plan["family"] == fam and plan["splitk"] == sk and plan["splitk_mode"] == 1, plan
+        first = [lay.step(c).clone() for c in range(3)]
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        outs = []
+        with torch.cuda.graph(graph):
+            for i in range(45):
+                outs.append(lay.step(i))
+        for _ in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, first[i % 3]) for i, o in enumerate(outs)), (M, N, K, sk, fam)
+        assert _state_words_clean(env)
+        del lay, outs, graph
+        torch.cuda.empty_cache()
+
+
+def test_skinny_grid_split(env):
+    """The skinny MFMA kernel with a grid-level K split (family 5 + splitk, round 4): the K slices of a 64-column slab are
+    neighbouring workgroups whose 4-KB partial tiles meet inside the launch (csrc/xwg.h, L form)."""
+    from flute_amd import dev
+    d = env.dev
+    for (tile_p, g, dtype, K, N) in [(32, 64, torch.float16, 4096, 1024), (64, 128, torch.bfloat16, 2048, 1024), (32, 32, torch.float16, 1024, 256),
+                                     (32, 64, torch.bfloat16, 14336, 512)]:
+        W, Q, S, table, table2 = make_case(env, 4, tile_p, g, dtype, K, N, seed=K % 91 + N % 5)
+        What = env.O.dequantize(Q.numpy(), S, table2, 4, g, tile_p).float()
+        tid = template_ids_for(env.fa, 4, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        for M in (3, 7, 16):
+            X = (torch.randn(M, K) / 100).to(dtype)
+            ks = torch.randint(0, K, (M,))
+            E = torch.zeros(M, K, dtype=dtype)
+            E[torch.arange(M), ks] = 1
+            ref = X.float() @ What
+            ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+            ran = 0
+            for sk in (2, 4, 7, 8, 14):
+                for waves in (-1, 4):
+                    ovr = dev.Overrides(family=5, splitk=sk, waves=waves)
+                    try:
+                        plan = dev.get_plan(M, N, K, 4, g, tid, env.num_sms, dtype, ovr)
+                    except RuntimeError:
+                        continue
+                    if plan["family"] != 5 or plan["splitk"] != sk:
+                        continue
+                    assert plan["ring_depth"] * plan["waves"] * 32 * sk == K and plan["grid"] == N // 64 * sk and plan["splitk_mode"] == 1
+                    ran += 1
+                    out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, 4, g, tid, env.num_sms, ovr)
+                    out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, 4, g, tid, env.num_sms, ovr)
+                    out2 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, 4, g, tid, env.num_sms, ovr)
+                    assert rel_err(out.cpu(), ref) < tol_of(dtype), (tile_p, g, dtype, K, N, M, sk, waves)
+                    if dtype == torch.float16:
+                        assert torch.equal(out1.cpu(), ref1), (tile_p, g, dtype, K, N, M, sk, waves)
+                    else:                                            # bf16: the scale is applied to the fp32 sum of a group run
+                        assert rel_err(out1.cpu(), ref1.float()) < tol_of(dtype)
+                    assert torch.equal(out, out2) and _state_words_clean(env), (tile_p, g, dtype, K, N, M, sk, waves)
+            assert ran, (K, g, M)
+
+
 # ---------------------------------------------------------------------------
 # full BASELINE shapes: size-independent properties, checker runs on the GPU
 # ---------------------------------------------------------------------------

@@ -28,7 +28,7 @@ UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip", "inst
          "inst_oneshot_skinny_b4.hip", "inst_splitk.hip"]
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*)\s+(\S+),")
+LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*|global_load_lds_\w+)\s+(\S+),")
 DSLOAD = re.compile(r"^\s*(ds_read_\w+)\s+(\S+),")
 VMCNT = re.compile(r"s_waitcnt\b.*vmcnt\((\d+)\)")
 LGKM = re.compile(r"s_waitcnt\b.*lgkmcnt\((\d+)\)")
@@ -163,7 +163,7 @@ def audit(path):
             ld = LOAD.match(text)
             dl = DSLOAD.match(text)
             if ld:
-                if re.search(r"\blds\s*$", text):             # LDS-DMA: the first operand is the address, no VGPR is written
+                if re.search(r"\blds\s*$", text) or ld.group(1).startswith("global_load_lds_"):   # LDS-DMA: the first operand is the address, no VGPR is written
                     dst, src = set(), regs_of(text[len(ld.group(1)):])
                 else:
                     dst = regs_of(ld.group(2))

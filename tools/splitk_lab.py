@@ -186,7 +186,83 @@ def timing(more=False):
     time_one(256, 4096, 4096, 2, f16, dict(family=6, splitk=4))
 
 
+def check_skinny():
+    """Skinny MFMA kernel (family 5) with a grid-level K split (xwg.h, L form)."""
+    nfail = 0
+    cases = [(32, 64, f16, 4096, 4096), (64, 64, bf16, 2048, 1024), (32, 128, f16, 4096, 512), (32, 32, f16, 1024, 256), (32, 64, f16, 8192, 2048),
+             (32, 64, bf16, 14336, 4096)]
+    for (tile_p, g, dtype, K, N) in cases:
+        torch.manual_seed(K + N)
+        W = torch.randint(0, 16, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(16, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = tid_of(4, tile_p)
+        Q = utils.pack(W, 4, [tid], num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        tol = 1e-3 if dtype == f16 else 8e-3
+        for M in (3, 5, 16):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for sk in (1, 2, 4, 7, 8, 14, 16):
+                for waves in (-1, 4):
+                    rec = {"kind": "check_skinny", "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "splitk": sk, "waves": waves}
+                    try:
+                        ovr = dev.Overrides(family=5, splitk=sk, waves=waves)
+                        try:
+                            pl = dev.get_plan(M, N, K, 4, g, tid, num_sms, dtype, ovr)
+                        except RuntimeError:
+                            continue
+                        if pl["family"] != 5 or pl["splitk"] != sk:
+                            continue
+                        o = dev.qgemm_planned(X, Q, S, table, table2, ws, 4, g, tid, num_sms, ovr)
+                        o1 = dev.qgemm_planned(E, Q, S, table, table2, ws, 4, g, tid, num_sms, ovr)
+                        o2 = dev.qgemm_planned(X, Q, S, table, table2, ws, 4, g, tid, num_sms, ovr)
+                        torch.cuda.synchronize()
+                        err = ((o.float() - ref).norm() / ref.norm()).item()
+                        exact = bool(torch.equal(o1, What[ks])) if dtype == f16 else bool(((o1.float() - What[ks].float()).abs() <= 8e-3 * What[ks].float().abs() + 1e-6).all())
+                        same = bool(torch.equal(o, o2))
+                        clean = state_clean()
+                        rec.update(err=err, onehot_exact=exact, repeat_identical=same, state_clean=clean, grid=pl["grid"], depth=pl["ring_depth"], kw=pl["kw"],
+                                   ok=bool(err < tol and exact and same and clean))
+                        if not clean:
+                            ws[:65536].zero_()
+                    except Exception as ex:  # noqa: BLE001
+                        rec.update(ok=False, error=str(ex)[:300])
+                    if not rec["ok"]:
+                        nfail += 1
+                    emit(rec)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    emit({"kind": "check_skinny_summary", "failed": nfail})
+    return nfail
+
+
+def time_skinny():
+    for (M, N, K) in ((16, 4096, 4096), (4, 4096, 4096), (16, 8192, 4096), (16, 6144, 4096), (16, 11008, 4096), (16, 4096, 14336), (16, 8192, 8192), (16, 2048, 8192)):
+        time_one(M, N, K, 4, f16, None)
+        for sk in (1, 2, 4, 7, 8, 14):
+            try:
+                pl = dev.get_plan(M, N, K, 4, 64, tid_of(4, 32), num_sms, f16, dev.Overrides(family=5, splitk=sk))
+            except RuntimeError:
+                continue
+            if pl["family"] == 5 and pl["splitk"] == sk:
+                time_one(M, N, K, 4, f16, dict(family=5, splitk=sk))
+
+
 rc = 0
+if "check_skinny" in what:
+    rc |= check_skinny()
+if "time_skinny" in what:
+    time_skinny()
+if "time_abl" in what:                                             # ablation builds (tools/splitk_ablate.sh): loop rates only
+    tag = os.path.basename(os.environ.get("FLUTE_AMD_LIB", "shipped"))
+    for sk in (1, 4):
+        time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
+    time_one(256, 11008, 4096, 4, f16, dict(family=6, splitk=1), tag=tag)
 if "check" in what:
     rc |= check()
 if "stress" in what:
