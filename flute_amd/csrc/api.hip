@@ -339,10 +339,10 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         if (sk > 1 && ((size_t)sk * tiles * 65536 > slab_room(workspace_bytes) || (size_t)sk * tiles * 65536 >= ((size_t)1 << 31))) return false;   // slabs: 64 KB per tile and slice
         return true;
     };
-    // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run5*.jsonl): a round of workgroups costs ~9.5 us of
-    // launch, prologue, K-half exchange and stores + 0.85 .. 1.0 us per 64-k step (the more of the chip is busy the slower:
-    // 37.0 us on 64 CUs, 41.8 on 256 at K = 4096); the seam grows with the MB published write-through
-    // (E form at 2 slices ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
+    // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run6*.jsonl): a round of workgroups costs ~9.5 us of
+    // launch, prologue, K-half exchange and stores + 0.75 .. 1.0 us per 64-k step (the more of the chip is busy the slower:
+    // 33.8 us on 64 CUs, 35.0 on 172, 39.8 on 224, 41.1 on 256 at K = 4096); the seam grows with the MB published
+    // write-through (E form at 2 slices ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
     auto model_us = [&](int sk) {
         const long wgs = tiles * sk;
         const long rounds = (wgs + num_sms - 1) / num_sms;
@@ -350,7 +350,7 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
         const double mb = sk == 1 ? 0.0 : (double)wgs * 0.065536 * ((sk == 2 || sk == 4) ? (sk - 1.0) / sk : 1.0);
         const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : 1.5 + 0.5 * mb);
-        return rounds * (9.5 + steps * (0.85 + 0.15 * fill)) + seam;
+        return rounds * (9.5 + steps * (0.75 + 0.24 * fill * fill * fill)) + seam;
     };
     int best = 0;
     double best_us = 0.0;
@@ -606,8 +606,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         }
         flute_plan q;
         double sk_us = 0.0;
+        // (one round of workgroups only: multi-round launches are left to the tuner's Stages-5 ids until measured)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, &q, 0, &sk_us) == FLUTE_OK && sk_us < 0.92 * alt_us &&
-            q.lds_bytes <= (size_t)kMaxLds) {
+            (long)q.grid <= (long)num_sms && q.lds_bytes <= (size_t)kMaxLds) {
             *p = q;
             return FLUTE_OK;
         }

@@ -15,7 +15,8 @@
 //     tools/stamps_skinny.py; block2's pieces are 16 rows x 64 B); fragment swizzle sk_swz (= qgemm_tile.h's swz_x);
 //   * the wave's scales for its whole K half are fetched once, by the prologue (<= 32 groups x 32 columns = 2 KB per
 //     wave): no scale request - and no sink request - per step;
-//   * a step's requests are 4 activation pieces + 2 weight pieces per wave, riding between the MFMAs of half step 0.
+//   * a step's requests are 4 activation pieces + ONE weight piece (whole lines too; the half step a lane lacks comes
+//     from its partner lane by DPP) per wave, riding between the MFMAs of half step 0.
 // Epilogue: (1) the two K halves exchange half of their row tiles through LDS (every wave ends with 4 row tiles x 2 column
 // tiles of the workgroup's K range), (2) splitk > 1: the E form of xwg.h when splitk is 2 or 4 (slice s owns row tile
 // s, s + nsh, ... of every wave), the L form otherwise; sums are taken in a fixed order (owner first, then the other slices
@@ -70,10 +71,11 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
 #else
     constexpr int dbg = 0;
 #endif
-    // A step's batch: 4 activation pieces + 2 weight pieces.  (Measured and dropped, profiles/r04/splitk_lab_run4_line_touch_
+    // A step's batch: 4 activation pieces + 1 weight piece.  (Measured and dropped, profiles/r04/splitk_lab_run4_line_touch_
     // prefetch_dropped.jsonl: one extra 4-B LDS-DMA per wave and step whose 64 lanes touch the 40 cache lines the wave will
     // want eight steps later - the requests are priced per LINE, so it doubled the addresser's work: 24.5 -> 27.8 us.)
-    constexpr int BATCH = ((dbg & 1) ? 0 : PPW) + ((dbg & 2) ? 0 : 2);
+    constexpr int NWQ = 1;                                         // weight requests per wave and step (one whole-line piece)
+    constexpr int BATCH = ((dbg & 1) ? 0 : PPW) + ((dbg & 2) ? 0 : NWQ);
     static_assert(BATCH <= RT, "one request per row tile of half step 0");
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
     constexpr int X_BASE = LUT_BYTES;
@@ -139,9 +141,14 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     }
     const uint32_t x_grp = (uint32_t)X_BASE + (uint32_t)kh * (BLK_STAGES * SK_STAGE);      // this K half's three stages
     const uint32_t x_lds0 = x_grp + (uint32_t)(wg * PPW) * 1024u;
-    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)q4 * 16u;
+    // Weights: ONE request per wave and step - 8 unit rows x 128 B, whole cache lines: lane (r16, q4) fetches chunk
+    // 4 (r16 >> 3) + q4 of unit r16 % U, i.e. the lanes of weight rows 0..7 hold half step 0's words and those of rows 8..15
+    // half step 1's (the same unit's other field).  The half a lane lacks comes from lane r16 ^ 8 of its 16-lane row by DPP
+    // (row_ror:8, four moves per half step).  (First version: two requests per step, each 16 half lines with lanes r16 and
+    // r16 + 8 reading the same 16 B; a request is priced per line it touches.)
+    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)((r16 >> 3) * 4 + q4) * 16u;
 
-    u32x4_t w[BLK_STAGES][2];
+    u32x4_t w[BLK_STAGES];
     // batch u = the hidden loads of this wave's K step u; batches past the end (issued two steps ahead, never consumed)
     // re-read the last step.  Every K offset is wave-uniform and travels in the scalar offset.
     auto issue_one = [&](auto slot_tag, auto i_tag, int u) {
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         constexpr int i = decltype(i_tag)::value;
         const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
         if constexpr (i < PPW) dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * SK_STAGE);
-        else w[slot][i - PPW] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)(i - PPW) * 64u);
+        else w[slot] = buf_load16(w_voff, w_srd, k0 * 2u);
     };
     // request j of a step's batch -> piece index (ablation builds drop the activation or the weight requests)
     auto issue_nth = [&](auto slot_tag, auto j_tag, int u) {
@@ -159,7 +166,16 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     auto issue_batch = [&](auto slot_tag, int u) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (issue_one(slot_tag, std::integral_constant<int, I>{}, u), ...);
-        }(std::make_integer_sequence<int, PPW + 2>{});
+        }(std::make_integer_sequence<int, PPW + NWQ>{});
+    };
+    // the words of half step h out of a step's piece: own where (r16 >> 3) == h, else the partner lane's
+    auto half_words = [&](const u32x4_t& own, auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+        u32x4_t r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128 /* row_ror:8 */, 0xf, h == 0 ? 0xc : 0x3, false);
+        return r;
     };
 
     // ---- pair-table words first (oldest in the queue: their wait below leaves everything else in flight) ----
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     // first two batches travel
 #pragma unroll
     for (int r = 0; r < LUT_R; ++r) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lutw[r]) : "n"(LUT_R - 1 - r + 2 + 2 * (PPW + 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lutw[r]) : "n"(LUT_R - 1 - r + 2 + 2 * (PPW + NWQ)) : "memory");
         const int p = tid + 512 * r;
         if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lutw[r], lutw[r], lutw[r], lutw[r]);
     }
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
             if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();   // (A) stage t-1 is free: batch t+2 follows, spread over the rows
         } else {
             // (B) batch t+1 has landed once at most batch t+2 is outstanding
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(BATCH) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(BATCH) : "memory");
             if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
         }
         u32x4_t bf[NT2];
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
             for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[h][c * 4 + ww], sj);
         }
         scales(nxt_t{}, t + h, nh);
-        const u32x4_t qw = w[nslot][nh];
+        const u32x4_t qw = half_words(w[nslot], nxt_t{});
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
 #pragma unroll
@@ -299,14 +315,14 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     };
 
     // scales, batch 0 and the pair table before anyone reads them
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(PPW + 2) : "memory");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(PPW + NWQ) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FLUTE_SKSTAMP(1);
     {
         using set0 = std::integral_constant<int, 0>;
         scales(set0{}, 0, 0);
-        const u32x4_t qw = w[0][0];
+        const u32x4_t qw = half_words(w[0], set0{});
         [&]<int... R>(std::integer_sequence<int, R...>) {
             (frag(set0{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
         }(std::make_integer_sequence<int, RT>{});
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
         if (t0 + 3 >= nsteps) break;
     }
     wait_lds(std::integral_constant<int, 0>{});                    // the prefetch past the end (set 0: the last half step is a half step 1)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : : "memory");
 
     FLUTE_SKSTAMP(2);
     // ---- epilogue 1: the K halves swap half of their row tiles through LDS (K half 0 keeps row tiles 0..3, K half 1

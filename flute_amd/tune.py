@@ -353,9 +353,44 @@ SUPPORTED_SHAPES = [
 EXTRA_SHAPES = [(11008, 4096), (4096, 11008), (3584, 8192)]       # BASELINE.json configs[1], TP-8 shard of configs[3]
 
 
+def challenge(M, N, K, num_bits, group_size, num_sms, dtype, device, incumbent: Optional[int], challengers: List[int],
+              tile_p: Optional[int] = None, rep: int = 40) -> Tuple[int, Dict[int, float]]:
+    """Time the table's current template id against a few named ids (e.g. the ids that select a NEW kernel) instead of the
+    whole template space: how a kernel added after the table was measured gets into it without a full re-tune."""
+    ids, seen = [], set()
+    for tid in ([incumbent] if incumbent is not None else []) + list(challengers):
+        if tid is None or (num_bits, tid) not in flute_amd.TEMPLATE_CONFIGS:
+            continue
+        if tile_p is not None and flute_amd.TEMPLATE_CONFIGS[(num_bits, tid)]["TileP"] != tile_p:
+            continue
+        if not utils.is_template_supported(M, N, K, num_bits, tid, num_sms, group_size, dtype):
+            continue
+        plan = utils.get_plan(M, N, K, num_bits, group_size, tid, num_sms, dtype)
+        key = (flute_amd.TEMPLATE_CONFIGS[(num_bits, tid)]["TileP"],) + tuple(sorted(plan.items()))
+        if key in seen:
+            continue
+        seen.add(key)
+        ids.append(tid)
+    if not ids:
+        raise RuntimeError("no candidate template")
+    bytes_per_copy = 2 * (N // 16 * num_bits) * K
+    copies = max(1, min(64, _L3_BYTES // max(bytes_per_copy, 1) + 1))
+    data = prepare_flute_data(M, N, K, num_bits, group_size, dtype, device, copies)
+    ws = utils.get_workspace_streamk(device)
+    times = {}
+    for tid in ids:
+        args = [(d["A"], d["Q"], d["S"], d["qmap"], d["qmap2"], ws, num_bits, group_size, tid, num_sms) for d in data]
+        times[tid] = do_bench(flute_amd.qgemm, args, rep=rep)
+    best = min(times, key=times.get)
+    if incumbent in times and times[incumbent] <= times[best] * 1.02:      # keep the incumbent inside the noise
+        best = incumbent
+    return best, times
+
+
 def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: float = 1e9, rep: int = 40,
-               retune: bool = False) -> Dict:
-    """flute/tune.py:466-494 (tune_tasks_legacy): time every task once on this GPU, persist the winners."""
+               retune: bool = False, challengers: Optional[List[int]] = None) -> Dict:
+    """flute/tune.py:466-494 (tune_tasks_legacy): time every task once on this GPU, persist the winners.
+    `challengers`: only time each key's current entry against these template ids (see `challenge`)."""
     import time
     device = torch.device("cuda")
     num_sms = utils.get_device_num_sms(device)
@@ -374,13 +409,17 @@ def tune_tasks(shapes, ms, bits_list, groups, dtypes, out_path: str, budget_s: f
                     for M in ms:
                         for tile_p in ((None,) if bits == 3 else (None, 32)):
                             k = tuned_key(M, N, K, bits, g, num_sms, dtype, tile_p)
-                            if k in entries and not retune:         # resume; --retune measures the requested keys again
+                            if k in entries and not retune and challengers is None:      # resume; --retune measures the requested keys again
                                 continue
                             if time.time() - t0 > budget_s:
                                 skipped += 1
                                 continue
                             try:
-                                tid = _tune(M, N, K, bits, g, num_sms, dtype, device, tile_p=32 if bits == 3 else tile_p, rep=rep)
+                                if challengers is not None:
+                                    tid, _ = challenge(M, N, K, bits, g, num_sms, dtype, device, entries.get(k), challengers,
+                                                       tile_p=32 if bits == 3 else tile_p, rep=rep)
+                                else:
+                                    tid = _tune(M, N, K, bits, g, num_sms, dtype, device, tile_p=32 if bits == 3 else tile_p, rep=rep)
                             except RuntimeError:
                                 continue
                             entries[k] = int(tid)
@@ -406,6 +445,7 @@ def _main() -> None:
     ap.add_argument("--budget-s", type=float, default=1e9)
     ap.add_argument("--rep", type=int, default=40)
     ap.add_argument("--retune", action="store_true", help="measure keys that already have an entry again (after a kernel change)")
+    ap.add_argument("--challenge", default="", help="template ids to time against each key's current entry, e.g. 12,28,60,76,108,124")
     a = ap.parse_args()
     if a.shapes == "supported":
         shapes = EXTRA_SHAPES + SUPPORTED_SHAPES
@@ -415,7 +455,8 @@ def _main() -> None:
         shapes = [tuple(int(v) for v in s.split(",")) for s in a.shapes.split(";")]
     dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}
     r = tune_tasks(shapes, [int(v) for v in a.ms.split(",")], [int(v) for v in a.bits.split(",")],
-                   [int(v) for v in a.groups.split(",")], [dt[v] for v in a.dtypes.split(",")], a.out, a.budget_s, a.rep, a.retune)
+                   [int(v) for v in a.groups.split(",")], [dt[v] for v in a.dtypes.split(",")], a.out, a.budget_s, a.rep, a.retune,
+                   [int(v) for v in a.challenge.split(",")] if a.challenge else None)
     print(json.dumps(r))
 
 

@@ -182,6 +182,13 @@ def timing(more=False):
         if M >= 256:
             time_one(M, N, K, 4, f16, dict(family=3, m_tiles=4))
         time_mm(M, N, K)
+    if more:
+        for (M, N, K) in ((2048, 4096, 4096), (4096, 4096, 4096), (1024, 11008, 4096), (2048, 11008, 4096), (1024, 8192, 8192), (512, 28672, 8192)):
+            time_one(M, N, K, 4, f16, None, steps=100)
+            time_one(M, N, K, 4, f16, dict(family=6, splitk=1), steps=100)
+            time_one(M, N, K, 4, f16, dict(family=3, m_tiles=4), steps=100)
+            time_one(M, N, K, 4, f16, dict(family=3, m_tiles=8), steps=100)
+            time_mm(M, N, K)
     time_one(256, 4096, 4096, 4, bf16, dict(family=6, splitk=4))
     time_one(256, 4096, 4096, 2, f16, dict(family=6, splitk=4))
 
