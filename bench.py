@@ -501,6 +501,15 @@ def main():
             tj = json.load(open(tpaths[-1]))
             if tj.get("plan") == plan:
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(tpaths[-1])
+        # the floor of THIS launch shape: a pure read of the same packed bytes, requested the way the kernel requests them, in
+        # the same kind of replayed graph (stand-alone harness, newest profiles/r*_calibration_stream_read.json)
+        floor_us, floor_src = None, None
+        cpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_calibration_stream_read.json")))
+        if cpaths:
+            reads = [r["us"] for r in json.load(open(cpaths[-1])).get("rows", [])
+                     if str(r.get("variant", "")).startswith("read_") and r.get("N") == N and r.get("K") == K and "nt" not in r["variant"]]
+            if reads:
+                floor_us, floor_src = min(reads), "profiles/" + os.path.basename(cpaths[-1])
         replicas = {
             "metric": "qgemm effective GB/s, M=1, W4G64 NF4 fp16, K=N=4096 (Llama-3-8B linear), HBM-cold",
             "parallelism": f"{world} independent replica(s), no collective"}
@@ -509,6 +518,8 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": traffic_src,
             "frac_of_measured_copy_6.29TBps": round(achieved / HBM_COPY_GBPS, 4),
+            "pure_read_floor_us": floor_us, "pure_read_floor_source": floor_src,
+            "frac_of_pure_read_floor": None if floor_us is None else round(floor_us / (ms_per_step * 1e3), 4),
             "bytes_per_launch": bytes_step,
             "kernel_us_events": round(ms_per_step * 1e3, 3),
             "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; traffic = "

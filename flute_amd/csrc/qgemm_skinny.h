@@ -307,7 +307,12 @@ __global__ __launch_bounds__(MAXW * 64) void qgemm_skinny_kernel(
             *reinterpret_cast<ushort4*>(Dout + (size_t)row * N + col) = o;
         }
     };
-    if (nsplit == 1) {
+#ifdef FLUTE_SK_ABLATE
+    constexpr bool no_seam = (FLUTE_SK_ABLATE & 128) != 0;         // development builds: every slice stores its partial as the result
+#else
+    constexpr bool no_seam = false;
+#endif
+    if (nsplit == 1 || no_seam) {
         for (int e = wave; e < NI; e += KW) {
             float4 s = red[e * 64 + lane];
             for (int ww = 1; ww < KW; ++ww) {

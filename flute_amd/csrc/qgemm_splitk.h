@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     constexpr int RT = SK_RT, NT2 = 2, NWN = 4;
     constexpr int PPW = RT * 2 / NWN;                              // activation pieces per wave and step (4)
 #ifdef FLUTE_SK_ABLATE   // development builds (tools/splitk_ablate.sh): 1 no activation requests in the loop, 2 no weight requests,
-    constexpr int dbg = FLUTE_SK_ABLATE;                           // 4 no MFMA, 8 no table lookups, 16 no fragment reads, 32 no barriers
+    constexpr int dbg = FLUTE_SK_ABLATE;                           // 4 no MFMA, 8 no table lookups, 16 no fragment reads, 32 no barriers, 128 no seam
 #else
     constexpr int dbg = 0;
 #endif
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col[t]) = o;
         }
     };
-    if (a.splitk == 1) {
+    if (a.splitk == 1 || (dbg & 128)) {                             // (ablation 128: every slice stores its partial as the result - the seam's price)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -270,6 +270,10 @@ if "time_abl" in what:                                             # ablation bu
     for sk in (1, 4):
         time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
     time_one(256, 11008, 4096, 4, f16, dict(family=6, splitk=1), tag=tag)
+    for sk in (2, 8):                                              # the seam's price: ablation 128 against the shipped library
+        time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
+    for (M, N, K, sk) in ((16, 4096, 4096, 4), (16, 4096, 4096, 2), (16, 8192, 4096, 2), (4, 4096, 4096, 4), (16, 2048, 8192, 8)):
+        time_one(M, N, K, 4, f16, dict(family=5, splitk=sk), tag=tag, steps=500)
 if "check" in what:
     rc |= check()
 if "stress" in what:
