@@ -493,6 +493,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // 4096^2 M = 4: 9.9 against 13.7 us; larger 3-bit layers are faster on the MFMA kernel.)
     const int dec_max = 4;
     const bool small_b3 = bits == 3 && ov.family < 0 && (size_t)N * K <= ((size_t)24 << 20);
+    // round 4: 2- / 4-bit layers up to 16 M weights take the four-row one-shot kernel at M = 3, 4 too (4096^2 M = 4: 6.3 us
+    // against 7.1 on the MFMA kernel, profiles/r04_planner_regret_before_fixes.json - the one-shot kernel of round 3 was not
+    // there when the MFMA kernel was measured level with the ring kernel)
+    const bool small_b24 = bits != 3 && ov.family < 0 && M >= 3 && (size_t)N * K <= ((size_t)16 << 20);
     const bool auto_digit = (bits == 4) ? (template_id % 4) == 0 : t.sms_multiple == 1;
     // decode planners: a fused Hadamard rotation prefers 8-wave workgroups (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with
     // the 4-wave shape the plain product takes)
@@ -500,12 +504,12 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     if (ov.had8 && ovd.waves < 0 && ovd.kw < 0 && ovd.one_shot != 0) ovd.waves = 8;
     auto persist_auto_ok = [&](int rows) {
         if (ov.one_shot >= 0 || ov.depth > 0 || ov.splitk > 1 || !auto_digit) return false;
-        if ((size_t)N * K < ((size_t)40 << 20) || (long)units < 6L * num_sms) return false;
+        if ((size_t)N * K < ((size_t)24 << 20) || (long)units < 4L * num_sms) return false;     // (round 4: from 40 M weights / 6 unit rows per CU - 6144 x 4096 M = 2 6.8 -> 6.0 us, 2-bit 10240 x 8192 M = 1 10.8 -> 9.8)
         flute_plan tmp;
         memset(&tmp, 0, sizeof(tmp));
         return plan_persist(bits, lg, rows, N, K, num_sms, t, ovd, &tmp, nullptr) == FLUTE_OK;
     };
-    int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3))) ? 0 : 2;
+    int family = (M <= 2 || (M <= dec_max && (ov.family == 0 || small_b3 || small_b24))) ? 0 : 2;
     if (ov.family >= 1) family = 2;               // any M may be forced through the MFMA kernel
     // Skinny MFMA kernel (qgemm_skinny.h): by override (family 5), by template (4-bit QuantMapMode digit 3 at M <= 16, where
     // the digit's other meaning - two slabs per wave - does not exist; digit 2: never), or automatically (digit 0) for
@@ -520,8 +524,22 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const bool fill5 = slabs5 * 20 >= 11L * num_sms && slabs5 <= num_sms;
         const bool auto5 = ov.family < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 &&
                            ((q4 == 0 && K >= 4096 && fill5) || q4 == 3);
-        if (ov.family == kFamilySkinny || auto5) {
-            if (plan_skinny(bits, lg, M, N, K, ov, workspace_bytes, p, oa) == FLUTE_OK) return FLUTE_OK;
+        // Round 4: narrower layers through a grid-level K split (the slices of a slab meet inside the launch, xwg.h: 1.5 - 1.7 us
+        // of seam, profiles/r04/xwg_seam_price.json) - the smallest power-of-two split that fills 55 % of the CUs, while a
+        // slice keeps >= 2048 k.  Measured (profiles/r04_planner_regret_before_fixes.json, us, per-wave kernel -> split skinny):
+        // M = 4: 3584 x 8192 10.1 -> 8.7, 8192^2 14.6 -> 13.0, 6144 x 4096 9.2 -> 8.5; M = 16: 3584 x 8192 10.2 -> 9.6; not
+        // taken: 4096^2 (four slices of 1024 k: 7.6 against 7.2).
+        int sk5 = 0;
+        if (ov.family < 0 && ov.splitk < 0 && family == 2 && bits == 4 && M >= 3 && M <= 16 && (q4 == 0 || q4 == 3) && K >= 4096 && !fill5 &&
+            slabs5 * 20 < 11L * num_sms) {
+            int sk = 2;
+            while (sk < 16 && slabs5 * sk * 20 < 11L * num_sms) sk *= 2;
+            if (slabs5 * sk <= num_sms && K / sk >= 2048) sk5 = sk;
+        }
+        if (ov.family == kFamilySkinny || auto5 || sk5) {
+            Ovr o5 = ov;
+            if (sk5) o5.splitk = sk5;
+            if (plan_skinny(bits, lg, M, N, K, o5, workspace_bytes, p, oa) == FLUTE_OK) return FLUTE_OK;
             memset(p, 0, sizeof(*p));
         }
     }
@@ -545,7 +563,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
-    //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89;
+    //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89 (round 2);
+    //   round 4 (2- / 4-bit blocks: whole-line activation pieces, one whole-line weight request per step):
+    //   256-row 97 / 120, bf16 101 / 124;  128-row 62 / 74, bf16 70 / 78 (profiles/r04/splitk_lab_run7*.jsonl);
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1;
     double alt_us = -1.0;                             // modelled time of the best other MFMA kernel (set by the block cost model)
@@ -560,7 +580,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (bits == 3 && ov.m_tiles != 8) blk_cfg = 5;   // 3-bit layers: 128-row blocks of qgemm_block3.h unless 256 rows are asked for ...
             if (bits == 3 && (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4))
                 blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
-        } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)48 << 20)) {
+        } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)56 << 20)) {    // (14336 x 3584, 51 M weights: 29.5 against 26.4 us on the per-wave kernel)
             // 3-bit skinny blocks (64 rows, grid K split): measured against the per-wave kernel at M = 64 - 8192^2 31.6 vs
             // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (fixed
             // costs of ~8 us per call: prologue, fp32 slabs, reduce launch)
@@ -576,13 +596,13 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // alone, 124 / 128 busy (profiles/r03/block_lab_w3_256_row_blocks.jsonl); the per-wave kernel runs them at
             // 330-380 TFLOP/s
             const double t256 = (bits == 3) ? block_us(tiles256, bf ? 118.0 : 108.0, bf ? 128.0 : 124.0)
-                                            : block_us(tiles256, bf ? 104.0 : 100.0, bf ? 129.0 : 126.0);
+                                            : block_us(tiles256, bf ? 101.0 : 97.0, bf ? 124.0 : 120.0);
             const double t128 = (bits == 3) ? block_us(tiles128, bf ? 85.0 : 78.0, bf ? 90.0 : 85.0)
-                                            : block_us(tiles128, bf ? 80.0 : 72.0, bf ? 89.0 : 81.0);
+                                            : block_us(tiles128, bf ? 70.0 : 62.0, bf ? 78.0 : 74.0);
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
             int dbl = 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;
-            const double wave_tf = (bits == 3) ? (bf ? 355.0 : 370.0)
+            const double wave_tf = (bits == 3) ? (bf ? 315.0 : 330.0)        // (round 4: 14336 x 3584 M = 256 runs at 305, modelled 370 kept it off the 128-row blocks: 86.4 against 70.3 us)
                                    : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl));
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;

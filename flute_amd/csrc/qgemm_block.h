@@ -51,6 +51,11 @@ constexpr int BLK_STAGES = 3;
 // to the fragment read): the 16 lanes of every ds_read_b128 lane group then hit 16 different bank slots
 __device__ __forceinline__ int blk_swz(int row) { return (4 - (row >> 2)) & 3; }
 
+// position swizzle of an 8-row x 8-chunk activation piece (rows 8 rh .. 8 rh + 7 of a 16-row tile, 128 B = one 64-k step
+// per row - whole cache lines, qgemm_block2.h since round 4): LDS position pos of row8 holds chunk pos ^ blk_swz8; the 16
+// lanes of every ds_read_b128 lane group then hit 16 different 16-B slots of the 256-B bank row (tests/test_splitk_layout.py)
+__host__ __device__ constexpr int blk_swz8(int row8, int rh) { return (row8 >> 1) | (rh << 2); }
+
 __host__ __device__ constexpr int block_lds_bytes(int bits, int tm, int wm, int wn) {
     const int lut = (1 << (2 * bits)) * 128;
     const int stage = wm * tm * 2 * 1024;                      // BM/16 row tiles x 2 half steps x 1 KB

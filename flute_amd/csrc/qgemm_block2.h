@@ -13,6 +13,11 @@
 // 8..15.  Two barriers per 64-k step: (A) at its start - every wave has retired its reads of stage t-1, batch t+2
 // may overwrite it; (B) at mid step - every wave's batch t+1 has landed, stage t+1 may be read.
 // Same arithmetic contract as qgemm_block.h: w^ = round_T(lut * s), fp32 accumulation, one output rounding.
+// Round 4 (what qgemm_splitk.h showed about requests - the CU's addresser is paid per cache line a request touches):
+// activation pieces are 8 rows x 128 B, whole lines (were 16 rows x 64 B), and a wave issues ONE whole-line weight request
+// per step (U unit rows x 128 B; the half step a lane lacks comes from lane r16 ^ 8 by DPP row_ror:8) instead of two that
+// touched 16 half lines each: 128-row blocks 72 -> 62.5 us per block at K = 4096, 256-row blocks 126.9 -> 123.0 us at
+// M = 4096 on 4096^2 (profiles/r04/splitk_lab_run7_block2_whole_line_requests.jsonl).
 #pragma once
 #include "qgemm_block.h"
 
@@ -34,11 +39,11 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     // the per-step costs - 8 lookups per wave, the DMA queue, two barriers - do not shrink with the rows; not instantiated)
     static_assert(RT == 16 || RT == 8 || RT == 4, "row tiles per block");
     constexpr bool SPLIT = __is_same(T, BF16) && RT == 16;         // batch issue spread over both half steps (below)
-    static_assert(RT * 2 / 8 + 3 <= RT, "the batch (PPW + 3 requests) is issued over the row tiles of a half step");
+    static_assert(RT * 2 / 8 + 2 <= RT, "the batch (PPW + 2 requests) is issued over the row tiles of a half step");
     constexpr int NS = RT < 8 ? RT : 8;                            // fragment slots
     constexpr int NW = 8, BM = RT * 16, NT2 = 2;                   // waves, rows, column tiles per wave
     constexpr int PIECES = RT * 2, PPW = PIECES / NW;
-    constexpr int BATCH = PPW + 2 + 1;                             // X pieces, two weight pieces, one scale block
+    constexpr int BATCH = PPW + 1 + 1;                             // X pieces, one weight piece, one scale block
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
     constexpr int STAGE_BYTES = PIECES * 1024;
 
@@ -87,23 +92,38 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
     const srd_t w_srd = make_srd(reinterpret_cast<const char*>(a.Q) + (size_t)unit0 * row_bytes, (uint32_t)U * row_bytes);
     const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
-    // Activations: this wave's PPW pieces are consecutive row tiles of one half (piece p = wave * PPW + i).  Rows
-    // past M need no flag: their byte offset is past the descriptor's range (voffset is what the range check
-    // covers) and reads as zero; the K offset of a step travels in the scalar offset.
-    constexpr int PH = PPW;                                        // pieces per wave, all of half (wave * PPW) / RT
+    // Activations (round 4: WHOLE cache lines - a request is priced per line it touches; before: 16 rows x 64 B): piece
+    // p = 2 rt + rh of a stage = rows 16 rt + 8 rh .. + 7, 128 B (the 64 k of the step) each; lane L fetches the 16-B chunk
+    // (L & 7) ^ blk_swz8(L >> 3, rh) of row L >> 3, written lane-linearly.  This wave's pieces: wave * PPW + i.  Rows past M
+    // need no flag: their byte offset is past the descriptor's range (voffset is what the range check covers) and reads
+    // as zero; the K offset of a step travels in the scalar offset.
+    constexpr int PH = PPW;
     const int p0 = wave * PPW;
-    const uint32_t x_v0 = (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
-                                      ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2);
-    const uint32_t x_dv = 16u * row_bytes;                         // next row tile
+    uint32_t x_vo[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int rt = (p0 + i) >> 1, rh = (p0 + i) & 1, row8 = lane >> 3;
+        x_vo[i] = (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ blk_swz8(row8, rh)) * 8)) * 2);
+    }
     const uint32_t x_lds0 = (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u;
-    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)q4 * 16u;
+    // Weights (round 4): ONE request per wave and step - U unit rows x 128 B, whole lines: lane (r16, q4) fetches chunk
+    // 4 (r16 >> 3) + q4 of unit r16 % U; the half step a lane lacks comes from lane r16 ^ 8 (same unit) by DPP row_ror:8
+    const uint32_t w_voff = (uint32_t)u8 * row_bytes + (uint32_t)((r16 >> 3) * 4 + q4) * 16u;
     // scale block: lane L < 32 fetches 8 groups of column (unit L % U, field L / U); the image is lane-linear
     const uint32_t s_voff = (lane < 32)
         ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane % U)) + (lane / U) * TILEP) * a.G) * 2) : 0x80000000u;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + BLK_STAGES * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
 
-    u32x4_t w[BLK_STAGES][2];
+    u32x4_t w[BLK_STAGES];
+    auto half_words = [&](const u32x4_t& own, auto h_tag) {         // the words of half step h out of a step's piece
+        constexpr int h = decltype(h_tag)::value;
+        u32x4_t r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128 /* row_ror:8 */, 0xf, h == 0 ? 0xc : 0x3, false);
+        return r;
+    };
     // batch u = every hidden load of K step u.  Batches past the end (issued two steps ahead, never consumed)
     // re-read the last step.  No per-lane arithmetic: every K offset is wave-uniform and travels in the scalar offset.
     auto issue_batch = [&](auto slot_tag, int u) {
@@ -111,9 +131,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
 #pragma unroll
         for (int i = 0; i < PH; ++i)
-            dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) w[slot][h] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)h * 64u);
+            dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+        w[slot] = buf_load16(w_voff, w_srd, k0 * 2u);
         const int g = (int)(k0 >> a.lg);
         const bool blk_start = (u < nsteps) && ((g & 7) == 0 || u == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
         // the block lands in this wave's image when the step starts one, else (same request) in the sink
@@ -128,9 +147,9 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         constexpr int i = decltype(i_tag)::value;
         const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
         if constexpr (i < PH) {
-            dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
-        } else if constexpr (i < PH + 2) {
-            w[slot][i - PH] = buf_load16(w_voff, w_srd, k0 * 2u + (uint32_t)(i - PH) * 64u);
+            dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+        } else if constexpr (i < PH + 1) {
+            w[slot] = buf_load16(w_voff, w_srd, k0 * 2u);
         } else {
             const int g = (int)(k0 >> a.lg);
             const bool blk_start = (u < nsteps) && ((g & 7) == 0 || u == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
@@ -149,8 +168,12 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         }
     }
     const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
-    const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(r16 * 4 + (q4 ^ blk_swz(r16))) * 16u;
-    const uint32_t frag_hi = frag_lo + 65536u;
+    // fragment of row tile R, half step h, stage slot: LUT + slot * STAGE_BYTES + R * 2048 + piece (r16 >> 3) * 1024 + row
+    // (r16 & 7) * 128 + position ((4 h + q4) ^ swz) * 16: the lane part in a base register per half step (+ 64 KB for the
+    // offsets past the 16-bit immediate), the rest immediate
+    const uint32_t frag_l0 = (uint32_t)LUT_BYTES + (uint32_t)((r16 >> 3) * 1024 + (r16 & 7) * 128 + ((q4 ^ blk_swz8(r16 & 7, r16 >> 3)) * 16));
+    const uint32_t frag_l1 = (uint32_t)LUT_BYTES + (uint32_t)((r16 >> 3) * 1024 + (r16 & 7) * 128 + (((4 + q4) ^ blk_swz8(r16 & 7, r16 >> 3)) * 16));
+    const uint32_t frag_h0 = frag_l0 + 65536u, frag_h1 = frag_l1 + 65536u;
     const uint32_t sc_lane = sc_base + (uint32_t)(fsel * U + u8) * 16u;
     const uint32_t shift0 = (uint32_t)(fsel * FB);                 // bit offset of this lane's field, column tile 0
 
@@ -179,9 +202,10 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     };
     auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
         constexpr int R = decltype(r_tag)::value;
-        constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + R) * 1024;
+        constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + R * 2048;
+        constexpr int hh = decltype(h_tag)::value;
         u32x4_t& dst = af[R & 7];
-        const uint32_t addr = off < 65536 ? frag_lo : frag_hi;
+        const uint32_t addr = off < 65536 ? (hh == 0 ? frag_l0 : frag_l1) : (hh == 0 ? frag_h0 : frag_h1);
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
     };
     auto wait_lds = [&]() {
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         } else {
             // (B) batch t+1 has landed once at most batch t+2 is outstanding (SPLIT: only its PH activation pieces have
             // been issued by now; its weight / scale requests follow during this half step)
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[nslot][0]), "+v"(w[nslot][1]) : "n"(SPLIT ? PH : BATCH) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(SPLIT ? PH : BATCH) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         u32x4_t bf[NT2];
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
             for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], sj);
         }
         scales(t + h, nh);
-        const u32x4_t qw = w[nslot][nh];
+        const u32x4_t qw = half_words(w[nslot], std::integral_constant<int, nh>{});
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
             if constexpr (R >= 8) {
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
             if constexpr (SPLIT) {
                 if constexpr (h == 0 && (R & 1) == 0 && R / 2 < PH)
                     issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, R / 2>{}, t + 2);
-                if constexpr (h == 1 && (R & 1) == 0 && R / 2 < 3)
+                if constexpr (h == 1 && (R & 1) == 0 && R / 2 < 2)
                     issue_one(std::integral_constant<int, (slot + 2) % BLK_STAGES>{}, std::integral_constant<int, PH + R / 2>{}, t + 2);
             } else {
                 if constexpr (h == 0 && R < BATCH)
@@ -265,12 +289,12 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     };
 
     // batch 0 and the pair table before anyone reads them
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(BATCH) : "memory");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(BATCH) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     scales(0, 0);
     {
-        const u32x4_t qw = w[0][0];
+        const u32x4_t qw = half_words(w[0], std::integral_constant<int, 0>{});
         [&]<int... R>(std::integer_sequence<int, R...>) {
             (frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}), ...);
         }(std::make_integer_sequence<int, NS>{});
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         if (t0 + 3 >= nsteps) break;
     }
     wait_lds();                                                    // the prefetch past the end
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : : "memory");
 
     // ---- epilogue: accumulator register i of lane (r16, q4) = weight row 4 q4 + i of the column tile = unit
     // (4 q4 + i) % 8, field q4 / 2 + 2 t: four consecutive columns; the lane's output row is r16 ----

@@ -64,8 +64,8 @@ def test_plan_families_and_invariants():
             rc, p = plan(M, 4096, 4096, bits=bits, tid=tid)
             assert rc == 0
             want = 0 if M <= 2 else 2                # decode kernel for M <= 2 (its 4-row variant on request), MFMA kernel beyond
-            if bits == 3 and M in (3, 4):
-                want = 0                             # small 3-bit layers: the 4-row decode variant is faster than their MFMA plans
+            if M in (3, 4):
+                want = 0                             # small layers (4096^2 = 16 M weights): the four-row decode kernels are faster than their MFMA plans (3 bits: round 2; 2 / 4 bits: round 4)
             if bits == 3 and M == 1000:
                 want = 3                             # 3 bits: the per-wave kernel is slow enough that 128 blocks already win
             if bits != 3 and M == 1000:
@@ -88,7 +88,8 @@ def test_plan_families_and_invariants():
     # small layers called with a Hadamard size (the rotation stays fused)
     lib = _lib.get()
     p = _lib.Plan()
-    assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(family=0), p) == 0
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 8192, 4096, 16, 256, 64 << 20, None, p) == 0 and p.family != 0    # 32 M weights: an MFMA kernel
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 8192, 4096, 16, 256, 64 << 20, _lib.Overrides(family=0), p) == 0
     assert p.family == 0 and p.m_block == 4
     assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 4096, 3584, 16, 256, 64 << 20) == 1
     assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 28672, 8192, 16, 256, 64 << 20) == 0
@@ -248,9 +249,13 @@ def test_plan_invariants_over_random_shapes():
             else:
                 assert p.ring_depth in (2, 4), what
         elif p.family == 5:                                       # skinny MFMA kernel
-            assert bits == 4 and 3 <= M <= 16 and p.splitk == 1 and p.workspace_needed == 0, what
-            assert p.ring_depth in (4, 8, 16) and p.ring_depth * p.waves * 32 == K and p.grid == N // 64, what
+            assert bits == 4 and 3 <= M <= 16 and p.splitk >= 1, what
+            assert p.ring_depth in (4, 8, 16) and p.ring_depth * p.waves * 32 * p.splitk == K and p.grid == N // 64 * p.splitk, what
             assert (K // g) % 2 == 0 and (p.ring_depth * 32) // g <= 8, what
+            if p.splitk > 1:                                      # grid-level K split inside the launch (round 4): 4 KB of slab per slice and slab
+                assert p.splitk_mode == 1 and p.workspace_needed == p.splitk * (N // 64) * 4096 + 65536 and p.grid <= num_sms and K // p.splitk >= 2048, what
+            else:
+                assert p.workspace_needed == 0, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
