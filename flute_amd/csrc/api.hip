@@ -340,8 +340,8 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         return true;
     };
     // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run6*.jsonl): a round of workgroups costs ~9.5 us of
-    // launch, prologue, K-half exchange and stores + 0.75 .. 1.0 us per 64-k step (the more of the chip is busy the slower:
-    // 33.8 us on 64 CUs, 35.0 on 172, 39.8 on 224, 41.1 on 256 at K = 4096); the seam grows with the MB published
+    // launch, prologue, K-half exchange and stores + 0.65 .. 0.96 us per 64-k step (the more of the chip is busy the slower:
+    // 30.3 us on 64 CUs, 32.9 on 172, 39.3 on 224, 40.3 on 256 at K = 4096, loader waves); the seam grows with the MB published
     // write-through (E form at 2 slices ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
     auto model_us = [&](int sk) {
         const long wgs = tiles * sk;
@@ -350,7 +350,7 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
         const double mb = sk == 1 ? 0.0 : (double)wgs * 0.065536 * ((sk == 2 || sk == 4) ? (sk - 1.0) / sk : 1.0);
         const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : 1.5 + 0.5 * mb);
-        return rounds * (9.5 + steps * (0.75 + 0.24 * fill * fill * fill)) + seam;
+        return rounds * (9.5 + steps * (0.65 + 0.31 * fill * fill * fill)) + seam;
     };
     int best = 0;
     double best_us = 0.0;
@@ -368,9 +368,12 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     if (cost_us) *cost_us = best_us;
     memset(p, 0, sizeof(*p));
     p->family = kFamilySplitK;
-    p->m_block = 0; p->m_tiles = 8; p->slabs_per_wave = 1; p->waves = 8; p->kw = 2;
+    // four loader waves beside the eight compute waves (round 4: K = 4096 per workgroup 34.1 -> 30.3 us on 64 CUs, 35.2 -> 32.9 on
+    // 172, 41.8 -> 40.3 on 256); override waves = 8: the variant without them
+    const int ldw = (ov.waves == 8) ? 0 : 4;
+    p->m_block = 0; p->m_tiles = 8; p->slabs_per_wave = 1; p->waves = 8 + ldw; p->kw = 2;
     p->splitk = best; p->k_per_split = K / best;
-    p->grid = (unsigned)(tiles * best); p->block = 512;
+    p->grid = (unsigned)(tiles * best); p->block = (unsigned)(512 + 64 * ldw);
     p->lds_bytes = (size_t)splitk_lds_bytes(bits); p->lut_copies = 32;
     p->splitk_mode = best > 1 ? 1 : 0;
     p->workspace_needed = best > 1 ? (size_t)best * tiles * 65536 + kXwgFlagBytes : 0;
@@ -858,9 +861,14 @@ int ensure_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
-bool hadamard_fusable(const flute_plan& p, int hadamard_size, int K) {
+// The decode kernels can rotate the activations while staging them - every workgroup rotates ALL rows for itself, so the
+// fused form costs ~0.33 us per 1024 elements of M x K (measured, profiles/r04/hadamard_fused_vs_separate.json: M = 1
+// K = 4096 +1.1 us, M = 1 K = 14336 +4.9, M = 4 K = 3584 +4.5) against ~3.1 us for the separate flute_hadamard launch:
+// fused only up to 8192 elements (or when the caller forces the decode family: tests, A/B runs).
+bool hadamard_worth_fusing(int M, int K, bool forced) { return forced || (size_t)M * K <= 8192; }
+bool hadamard_fusable(const flute_plan& p, int hadamard_size, int M, int K, bool forced) {
     return p.family == 0 && hadamard_size >= 2 && hadamard_size <= 512 &&
-           (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0;
+           (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0 && hadamard_worth_fusing(M, K, forced);
 }
 
 }  // namespace
@@ -918,16 +926,13 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
                           workspace, workspace_bytes, template_id, num_sms, nullptr, stream);
 }
 
-// M = 3, 4 with a Hadamard pre-rotation: the four-row decode kernel keeps the rotation fused (one launch) - worth
-// more than the MFMA kernel's edge on layers up to 32 M weights (4096x3584: 8.7 us fused vs 7.6 + a rotation launch)
+// Calls that will fuse the rotation prefer 8-wave workgroups: the rotation is done by the workgroup's waves, 512 k each - 8 waves
+// rotate a 4096-k row in one pass (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with the 4-wave shape the plain product prefers).
+// (Applied inside the decode branch of the planner only: make_plan_uncached.  Round 3 also forced the four-row decode
+// kernel at M = 3, 4 to keep the rotation fused: measured again in round 4, the fused form loses there - above.)
 static Ovr hadamard_ovr(Ovr o, int hadamard_size, int bits, int M, int N, int K) {
-    if (hadamard_size > 1 && hadamard_size <= 512 && o.family < 0 && M >= 3 && M <= 4 &&
-        (size_t)N * K <= ((size_t)32 << 20))
-        o.family = 0;
-    // the fused rotation is done by the workgroup's waves, 512 k each: 8 waves rotate a 4096-k row in one pass
-    // (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with the 4-wave shape the plain product prefers)
-    // (applied inside the decode branch of the planner only: make_plan_uncached)
-    if (hadamard_size > 1 && hadamard_size <= 512 && M <= 4) o.had8 = 1;
+    (void)bits; (void)N;
+    if (hadamard_size > 1 && hadamard_size <= 512 && M <= 4 && hadamard_worth_fusing(M, K, o.family == 0)) o.had8 = 1;
     return o;
 }
 
@@ -937,7 +942,7 @@ int flute_qgemm_hadamard_fused(int dtype, int num_bits, int group_size, int hada
     if (make_plan(dtype, num_bits, group_size, M, N, K, template_id, num_sms, workspace_bytes,
                   hadamard_ovr(ovr_of(nullptr), hadamard_size, num_bits, M, N, K), &p, nullptr, nullptr, nullptr))
         return 0;
-    return hadamard_fusable(p, hadamard_size, K) ? 1 : 0;
+    return hadamard_fusable(p, hadamard_size, M, K, false) ? 1 : 0;
 }
 
 int flute_qgemm_hadamard(int dtype, int num_bits, int group_size, int hadamard_size, int M, int N,
@@ -971,7 +976,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
 
     int had_log = 0;
     if (hadamard_size > 1) {
-        if (hadamard_fusable(p, hadamard_size, K)) {
+        if (hadamard_fusable(p, hadamard_size, M, K, ovr && ovr->family == 0)) {
             had_log = ilog2(hadamard_size);              // rotated inside the decode kernel's staging
         } else {
             // two launches (qgemm.cpp:201-244): rotate into the caller's scratch, then the plain product
@@ -1083,7 +1088,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
         b.tiles_m = ceil_div(M, 128);
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
-        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p);
+        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.waves == 12 ? 4 : 0);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&b};

@@ -56,8 +56,20 @@ __host__ __device__ constexpr int splitk_lds_bytes(int bits) {
     return (128 << (2 * bits)) + 2 * BLK_STAGES * SK_STAGE + 8 * SK_SCALE_WAVE;
 }
 
-template <typename T, int TILEP, int BITS = 4>
-__global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args) {
+// LDW = 4: four LOADER waves beside the eight compute waves (block of 768 threads).  A loader issues the activation
+// pieces of both K halves (8 per step) and nothing else; the compute waves are left with one weight request per step -
+// their in-order instruction streams no longer stall in the addresser's queue between MFMAs.  Same barriers, same stages.
+// A hidden load's value, handed over in a NEW register once at most N younger loads are outstanding.  (The wait and the
+// move are one asm statement: with the usual "+v" wait hipcc was seen copying the destination into the first register
+// of the quad the table store wants BEFORE the wait - the audit caught it in the 768-thread variant.)
+template <int N> __device__ __forceinline__ uint32_t lut_word_after(const uint32_t& hidden) {
+    uint32_t v;
+    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, %1" : "=&v"(v) : "v"(hidden), "n"(N) : "memory");
+    return v;
+}
+
+template <typename T, int TILEP, int BITS = 4, int LDW = 0>
+__global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const SplitKArgs args) {
     using NT = Num<T>;
     static_assert(BITS == 4 || BITS == 2, "3-bit layers: qgemm_block3.h / qgemm_tile.h");
     constexpr int J = 16 / BITS;
@@ -65,7 +77,10 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     constexpr int FPT = 16 / U;                                    // fields per column tile and unit
     constexpr int FB = 2 * BITS;
     constexpr int RT = SK_RT, NT2 = 2, NWN = 4;
-    constexpr int PPW = RT * 2 / NWN;                              // activation pieces per wave and step (4)
+    static_assert(LDW == 0 || LDW == 4, "loader waves");
+    constexpr int NTHR = 512 + 64 * LDW;
+    constexpr int PPW = LDW ? 0 : RT * 2 / NWN;                    // activation pieces per COMPUTE wave and step (4; none with loaders)
+    constexpr int LPW = LDW ? 2 * RT * 2 / LDW : 0;                // ... per LOADER wave and step (both K halves: 32 / 4)
 #ifdef FLUTE_SK_ABLATE   // development builds (tools/splitk_ablate.sh): 1 no activation requests in the loop, 2 no weight requests,
     constexpr int dbg = FLUTE_SK_ABLATE;                           // 4 no MFMA, 8 no table lookups, 16 no fragment reads, 32 no barriers, 128 no seam
 #else
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     // position pos of row8 holds chunk pos ^ swz.  This wave's pieces: 4 wg .. 4 wg + 3 (row tiles 2 wg, 2 wg + 1).
     // Rows past M: their byte offset is past the descriptor's range and reads as zero (voffset is what is checked).
     const int row8 = lane >> 3;
-    uint32_t x_vo[PPW];
+    uint32_t x_vo[PPW ? PPW : 1];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int rt = wg * 2 + (i >> 1), rh = i & 1;
@@ -180,11 +195,51 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
 
     // ---- pair-table words first (oldest in the queue: their wait below leaves everything else in flight) ----
     constexpr int ENT = 1 << (2 * BITS);
-    constexpr int LUT_R = (ENT * 8 + 511) / 512;                   // 16-B table pieces per thread
+    constexpr int LUT_R = (ENT * 8 + NTHR - 1) / NTHR;             // 16-B table pieces per thread
     const srd_t lut_srd = make_srd(a.QM2, (uint32_t)(4 * ENT));
     uint32_t lutw[LUT_R];
 #pragma unroll
-    for (int r = 0; r < LUT_R; ++r) lutw[r] = buf_load4((uint32_t)((tid + 512 * r) >> 3) * 4u, lut_srd);   // past the table: reads 0, not written
+    for (int r = 0; r < LUT_R; ++r) lutw[r] = buf_load4((uint32_t)((tid + NTHR * r) >> 3) * 4u, lut_srd);   // past the table: reads 0, not written
+    if constexpr (LDW > 0) {
+        if (wave >= 8) {
+            // ---- loader wave L: K half L / 2, pieces 8 (L % 2) .. + 7 of that half's stage, every step ----
+            const int L = wave - 8, lkh = L >> 1, lp0 = (L & 1) * LPW;
+            const int lkbeg = split * a.k_per_split + lkh * khalf;
+            uint32_t lx[LPW];
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) {
+                const int rt = (lp0 + i) >> 1, rh = (lp0 + i) & 1;
+                lx[i] = (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ sk_swz(row8, rh)) * 8)) * 2);
+            }
+            const uint32_t ldst = (uint32_t)X_BASE + (uint32_t)lkh * (BLK_STAGES * SK_STAGE) + (uint32_t)lp0 * 1024u;
+            auto lbatch = [&](int u) {
+                const uint32_t k0 = (uint32_t)(lkbeg + min(u, nsteps - 1) * 64);
+                const uint32_t dst = ldst + (uint32_t)(u % BLK_STAGES) * SK_STAGE;
+#pragma unroll
+                for (int i = 0; i < LPW; ++i) dma16_buf(lx[i], x_srd, k0 * 2u, dst + (uint32_t)i * 1024u);
+            };
+            lbatch(0);
+            lbatch(1);
+            [&]<int... R>(std::integer_sequence<int, R...>) {
+                ([&] {
+                    const uint32_t lv = lut_word_after<LUT_R - 1 - R + 2 * LPW>(lutw[R]);
+                    const int p = tid + NTHR * R;
+                    if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lv, lv, lv, lv);
+                }(), ...);
+            }(std::make_integer_sequence<int, LUT_R>{});
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW) : "memory");       // batch 0 has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int t = 0; t < nsteps; ++t) {
+                __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free
+                lbatch(t + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW) : "memory");   // (B) batch t+1 has landed
+                __builtin_amdgcn_s_barrier();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;                                                // the epilogue's barriers count the live waves only
+        }
+    }
     // ---- scales of the whole K half, once: 8-group blocks from the block that holds the first group.  Request r, lane L:
     // block 2 r + L / 32 of column (unit L % U, field (L & 31) / U); image [block][column] x 16 B, lane-linear ----
     const int g0e = (kbeg >> a.lg) & ~7;
@@ -199,12 +254,13 @@ __global__ __launch_bounds__(512) void qgemm_splitk_kernel(const SplitKArgs args
     issue_batch(std::integral_constant<int, 1>{}, 1);
     // the pair table (entry e: 32 copies of its word at [128 e, 128 e + 128)) is written while the scale blocks and the
     // first two batches travel
-#pragma unroll
-    for (int r = 0; r < LUT_R; ++r) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lutw[r]) : "n"(LUT_R - 1 - r + 2 + 2 * (PPW + NWQ)) : "memory");
-        const int p = tid + 512 * r;
-        if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lutw[r], lutw[r], lutw[r], lutw[r]);
-    }
+    [&]<int... R>(std::integer_sequence<int, R...>) {
+        ([&] {
+            const uint32_t lv = lut_word_after<LUT_R - 1 - R + 2 + 2 * (PPW + NWQ)>(lutw[R]);
+            const int p = tid + NTHR * R;
+            if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lv, lv, lv, lv);
+        }(), ...);
+    }(std::make_integer_sequence<int, LUT_R>{});
     const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
     // fragment of row tile R, half step h, stage slot: x_grp + slot * SK_STAGE + R * 2048 + piece (r16 >> 3) * 1024 + row
     // (r16 & 7) * 128 + position ((4 h + q4) ^ swz) * 16; the lane part lives in two base registers, the rest is immediate

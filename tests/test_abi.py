@@ -72,7 +72,7 @@ def test_plan_families_and_invariants():
                 want = 6                             # 2 / 4 bits: 8 x 32 tiles of 128 x 128, one per CU (qgemm_splitk.h, round 4)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
             if p.family == 6:
-                assert (p.grid, p.block, p.splitk, p.workspace_needed) == (256, 512, 1, 0)
+                assert (p.grid, p.block, p.splitk, p.workspace_needed) == (256, 768, 1, 0)      # 8 compute + 4 loader waves
                 continue
             if p.family == 2:
                 assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)
@@ -91,10 +91,15 @@ def test_plan_families_and_invariants():
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 8192, 4096, 16, 256, 64 << 20, None, p) == 0 and p.family != 0    # 32 M weights: an MFMA kernel
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 4, 8192, 4096, 16, 256, 64 << 20, _lib.Overrides(family=0), p) == 0
     assert p.family == 0 and p.m_block == 4
-    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 4096, 3584, 16, 256, 64 << 20) == 1
+    # the rotation is fused into a decode plan only while it is cheaper than a separate launch: M x K <= 8192 elements
+    # (every workgroup rotates all rows for itself; measured in round 4, profiles/r04/hadamard_fused_vs_separate.json)
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 1, 4096, 3584, 16, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 2, 4096, 3584, 16, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 4096, 3584, 16, 256, 64 << 20) == 0
     assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 4, 28672, 8192, 16, 256, 64 << 20) == 0
-    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 2, 28672, 8192, 16, 256, 64 << 20) == 1
-    assert lib.flute_qgemm_hadamard_fused(1, 3, 64, 512, 3, 4096, 4096, 4, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 1, 28672, 8192, 16, 256, 64 << 20) == 1
+    assert lib.flute_qgemm_hadamard_fused(0, 4, 64, 512, 2, 28672, 8192, 16, 256, 64 << 20) == 0
+    assert lib.flute_qgemm_hadamard_fused(1, 3, 64, 512, 2, 4096, 4096, 4, 256, 64 << 20) == 1
     # no workspace -> never a grid-level K split
     for M in (1, 16, 64):
         rc, p = plan(M, 512, 16384, ws=0)
@@ -262,7 +267,7 @@ def test_plan_invariants_over_random_shapes():
             assert bits != 3 or p.m_block == 1, what
         elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
             tiles = -(-M // 128) * (N // 128)
-            assert bits in (2, 4) and M >= 128 and p.block == 512 and p.grid == tiles * p.splitk, what
+            assert bits in (2, 4) and M >= 128 and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
             assert p.k_per_split * p.splitk == K and p.k_per_split % (2 * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
             gh = p.k_per_split // 2 // g
             assert gh + (7 if gh % 8 else 0) <= 32, what
@@ -306,12 +311,12 @@ def test_qgemm_hadamard_entry_host_logic():
     lib = _lib.get()
     ws = 64 << 20
     fused = lambda M, K, h, bits=4, tid=16: lib.flute_qgemm_hadamard_fused(0, bits, 64, h, M, 4096, K, tid, 256, ws)  # noqa: E731
-    assert fused(1, 4096, 512) == 1 and fused(4, 4096, 16) == 1 and fused(1, 3584, 512) == 1
+    assert fused(1, 4096, 512) == 1 and fused(4, 2048, 16) == 1 and fused(1, 3584, 512) == 1 and fused(4, 4096, 16) == 0
     assert fused(5, 4096, 512) == 0          # MFMA plan: rotated into the caller's scratch first
     assert fused(1, 4096, 1024) == 0         # block wider than one wave's 512-element span
     assert fused(1, 4096 + 64, 512) == 0     # blocks would straddle rows
     assert fused(1, 4096, 48) == 0           # not a power of two
-    assert fused(3, 4096, 512, bits=3, tid=4) == 1 and fused(2, 4096, 512, bits=3, tid=4) == 1     # 3 bits: four rows too
+    assert fused(3, 2048, 512, bits=3, tid=4) == 1 and fused(2, 4096, 512, bits=3, tid=4) == 1     # 3 bits: four rows too
     head = [0, 4, 64, 512, 0, 4096, 4096, 1024]
     tail = [None] * 8 + [0, 16, 256, None]
     assert lib.flute_qgemm_hadamard(*(head + tail)) == 0            # M == 0

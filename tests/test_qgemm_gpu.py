@@ -514,7 +514,7 @@ def test_splitk_block_kernel(env):
                     plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
                 except RuntimeError:
                     continue                                      # not a legal split of this K (qgemm_splitk.h's host contract)
-                assert plan["family"] == 6 and plan["splitk"] == sk and plan["grid"] == -(-M // 128) * (N // 128) * sk
+                assert plan["family"] == 6 and plan["splitk"] == sk and plan["grid"] == -(-M // 128) * (N // 128) * sk and plan["waves"] == 12
                 ran.add(sk)
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
@@ -523,6 +523,9 @@ def test_splitk_block_kernel(env):
                 assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk)
                 assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk)
                 assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk)
+                if M in (130, 700) and sk in (1, 2, 3):              # the variant without loader waves: the same numbers
+                    o8 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=6, splitk=sk, waves=8))
+                    assert torch.equal(o8, out), (bits, tile_p, g, dtype, K, N, M, sk)
             assert 1 in ran or g == 32 and K > 2048, (K, g, ran)
             assert len(ran) >= 3, (K, g, ran)
     # the planner takes it by itself where it was measured faster (profiles/r04): one workgroup per tile on the MLP widths
@@ -759,14 +762,20 @@ def test_qgemm_hadamard_fused_equals_two_launches(env):
             if K % h:
                 continue
             for M in (1, 2, 3, 4):
-                assert lib.flute_qgemm_hadamard_fused(0 if dtype == torch.float16 else 1, bits, g, h, M, N, K,
-                                                      tid, env.num_sms, env.ws.numel()) == 1
+                # the operator fuses while the rotation is cheaper inside the kernel than as a launch of its own (M x K <= 8192,
+                # round 4); forcing the decode family fuses regardless - both forms against rotate-then-multiply
+                auto_fused = lib.flute_qgemm_hadamard_fused(0 if dtype == torch.float16 else 1, bits, g, h, M, N, K,
+                                                            tid, env.num_sms, env.ws.numel())
+                assert auto_fused == (1 if M * K <= 8192 else 0), (bits, K, h, M)
                 X = (torch.randn(M, K) / 10).to(dtype).to(d)
-                fused = env.fa.qgemm_hadamard(X, Qd, Sd, td, t2d, env.ws, bits, g, h, tid, env.num_sms)
-                # the same kernel on pre-rotated activations (M = 3, 4: the plain product would take the MFMA kernel)
+                fused = dev.qgemm_planned(X, Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=0), hadamard_size=h)
+                # the same kernel on pre-rotated activations (M = 3, 4: the plain product may take another kernel)
                 two = dev.qgemm_planned(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, bits, g, tid,
                                         env.num_sms, dev.Overrides(family=0))
                 assert torch.equal(fused, two), (bits, dtype, K, h, M)
+                auto = env.fa.qgemm_hadamard(X, Qd, Sd, td, t2d, env.ws, bits, g, h, tid, env.num_sms)
+                plain = env.fa.qgemm(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms)
+                assert torch.equal(auto, plain) or rel_err(auto.cpu(), plain.float().cpu()) < 5e-4, (bits, dtype, K, h, M)
     # plans that cannot fuse (MFMA kernel, blocks larger than 512) take the scratch path
     bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 2048, 512
     W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=2)

@@ -97,7 +97,9 @@ def _plan(M, N, K, bits=4, g=64, tid=16, ws=64 << 20, dtype=0, **ovr):
 
 def test_plan_family6():
     rc, p = _plan(256, 4096, 4096, family=6)
-    assert rc == 0 and p.family == 6 and p.block == 512 and p.waves == 8 and p.kw == 2
+    assert rc == 0 and p.family == 6 and p.block == 768 and p.waves == 12 and p.kw == 2      # 8 compute + 4 loader waves
+    rc8, p8 = _plan(256, 4096, 4096, family=6, waves=8)
+    assert rc8 == 0 and p8.block == 512 and p8.waves == 8                                    # the variant without loader waves
     assert p.splitk == 2 and p.k_per_split == 2048 and p.grid == 128 and p.splitk_mode == 1     # (measured: 24.1 us, four slices 25.1)
     assert p.workspace_needed == 2 * 64 * 65536 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384   # 64 KB per tile and slice
     assert _plan(256, 4096, 4096, family=6, splitk=16)[0] != 0         # 64 MiB of slabs + the state words: one page too many

@@ -260,7 +260,87 @@ def time_skinny():
                 time_one(M, N, K, 4, f16, dict(family=5, splitk=sk))
 
 
+def check_ldw():
+    """The loader-wave variant (override waves = 12) on a subset of check()'s cases."""
+    nfail = 0
+    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
+                                           (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (4, 32, 32, f16, 1024, 256)]:
+        torch.manual_seed(K + N)
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(2 ** bits, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = tid_of(bits, tile_p)
+        Q = utils.pack(W, bits, [tid], num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        tol = 1e-3 if dtype == f16 else 8e-3
+        for M in (1, 130, 256, 700):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for sk in (1, 2, 3, 4, 8):
+                rec = {"kind": "check_ldw", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "splitk": sk}
+                try:
+                    ovr = dev.Overrides(family=6, splitk=sk, waves=12)
+                    try:
+                        pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
+                    except RuntimeError:
+                        continue
+                    assert pl["waves"] == 12 and pl["block"] == 768
+                    o = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    o1 = dev.qgemm_planned(E, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    o2 = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    torch.cuda.synchronize()
+                    err = ((o.float() - ref).norm() / ref.norm()).item()
+                    rec.update(err=err, onehot_exact=bool(torch.equal(o1, What[ks])), repeat_identical=bool(torch.equal(o, o2)), state_clean=state_clean())
+                    rec["ok"] = bool(err < tol and rec["onehot_exact"] and rec["repeat_identical"] and rec["state_clean"])
+                    if not rec["state_clean"]:
+                        ws[:65536].zero_()
+                except Exception as ex:  # noqa: BLE001
+                    rec.update(ok=False, error=str(ex)[:300])
+                if not rec["ok"]:
+                    nfail += 1
+                emit(rec)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    emit({"kind": "check_ldw_summary", "failed": nfail})
+    return nfail
+
+
+def time_ldw():
+    for (M, N, K, sk) in ((256, 11008, 4096, 1), (1024, 4096, 4096, 1), (256, 4096, 4096, 1), (256, 4096, 4096, 2), (256, 4096, 4096, 4), (256, 14336, 4096, 1),
+                          (256, 8192, 8192, 2), (512, 4096, 4096, 2), (128, 11008, 4096, 2)):
+        for waves in (-1, 12):
+            time_one(M, N, K, 4, f16, dict(family=6, splitk=sk, waves=waves))
+    time_one(256, 11008, 4096, 4, bf16, dict(family=6, splitk=1, waves=12))
+    time_one(256, 11008, 4096, 2, f16, dict(family=6, splitk=1, waves=12))
+
+
+def time_had():
+    """What the UNFUSED rotation costs at 5 <= M <= 16 (SURVEY f-3): flute.qgemm_hadamard(h = 512) against flute.qgemm on the
+    Gemma-2-9B shapes - the difference is the separate flute_hadamard launch a fused prologue would save at most."""
+    for (N, K) in ((4096, 3584), (14336, 3584), (3584, 14336), (4096, 4096)):
+        for M in (1, 4, 16):
+            us = {}
+            for had in (0, 512):
+                lay = bench.Layer(M, N, K, 4, 64, f16, d, bench.copies_for(N, K, 4), hadamard_size=had)
+                lay.tune()
+                ms = min(bench.time_graph(lay, 300, 5, torch.cuda.synchronize)[0] for _ in range(2))
+                us[had] = round(ms / 300 * 1e3, 2)
+                del lay
+                torch.cuda.empty_cache()
+            emit({"kind": "time_had", "M": M, "N": N, "K": K, "qgemm_us": us[0], "qgemm_hadamard_us": us[512], "rotation_us": round(us[512] - us[0], 2)})
+
+
 rc = 0
+if "time_had" in what:
+    time_had()
+if "check_ldw" in what:
+    rc |= check_ldw()
+if "time_ldw" in what:
+    time_ldw()
 if "check_skinny" in what:
     rc |= check_skinny()
 if "time_skinny" in what:
