@@ -99,7 +99,8 @@ typedef struct flute_plan {
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
  *   family          5 skinny MFMA kernel (4-bit, M <= 16; waves 4 / 8 picks the in-workgroup K split);
- *                   6 split-K block kernel (splitk picks the K slices per 128 x 128 tile; 1 = none);
+ *                   6 split-K block kernel (splitk picks the K slices per 128 x 128 tile; 1 = none; waves 8 = without the
+ *                   four loader waves);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
  *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)
@@ -131,8 +132,8 @@ int flute_qgemm(int dtype, int num_bits, int group_size, int M, int N, int K, in
 
 /* flute.qgemm_hadamard (flute/__init__.py:32-50; apply_hadamard + qgemm_raw_simple_hadamard,
  * flute/csrc/qgemm.cpp:201-244): D = (A.reshape(-1, hadamard_size) @ H/sqrt(hadamard_size)).reshape(M,K)
- * @ dequant(Q).  When the launch plan is the decode kernel (M <= 2; M <= 4 on layers up to 32 M weights) and
- * hadamard_size <= 512 divides K,
+ * @ dequant(Q).  When the launch plan is a decode kernel, hadamard_size <= 512 divides K and M * K <= 8192 elements
+ * (every workgroup rotates all M rows for itself: beyond that a separate flute_hadamard launch is cheaper - measured),
  * the rotation is fused into that kernel's activation staging (one launch, no round trip of the
  * rotated activations through HBM; same fp32 butterflies and single rounding as flute_hadamard, so the
  * result is bit-identical to the two-launch form).  Otherwise the rotated activations go to

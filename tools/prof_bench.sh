@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the bench command (run on the GPU box): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in their own PMC passes (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE x2 correction on gfx950).
-# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r03_bench_traffic.json - the file bench.py
+# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r04_bench_traffic.json - the file bench.py
 # reads `roofline.traffic` from (copy it to profiles/; it carries the plan it was measured on and bench.py
 # drops it the moment the live plan differs).
 set -u
@@ -42,6 +42,6 @@ rec = {"source": "tools/prof_bench.sh: rocprofv3 --kernel-trace --stats, then --
        "correction": "gfx950: FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled",
        "hbm_bytes_per_launch": None if fetch is None else (2 * fetch + (write or 0)) * 1024,
        "kernel_trace": trace, "bench_untraced_ms_per_step": line["ms_per_step"]}
-json.dump(rec, open(out + "/r03_bench_traffic.json", "w"), indent=1)
+json.dump(rec, open(out + "/r04_bench_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
