@@ -1088,6 +1088,11 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
         b.tiles_m = ceil_div(M, 128);
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
+        b.pair_lg = -1; b.pair_c8 = 0;
+        if (p.splitk == 1 && b.tiles_m >= 2 && b.tiles_m % 2 == 0 && ((b.tiles_m / 2) & (b.tiles_m / 2 - 1)) == 0) {
+            b.pair_lg = ilog2(b.tiles_m / 2);
+            b.pair_c8 = ((b.tiles_m / 2) * (N / 128)) & ~7;
+        }
         SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.waves == 12 ? 4 : 0);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;

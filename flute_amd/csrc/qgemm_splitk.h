@@ -43,6 +43,9 @@ struct SplitKArgs {
     int M, N, K, G, lg;
     int tiles_m;            // 128-row tiles (fastest in the block order: the row tiles of a column tile are neighbours)
     int splitk, k_per_split;
+    // XCD-aware tile order (splitk == 1, tiles_m = 2 P with P a power of two): pair_lg = log2(P), pair_c8 = (P x column tiles)
+    // rounded down to a multiple of 8; pair_lg < 0: tiles in their natural order
+    int pair_lg, pair_c8;
 };
 
 constexpr int SK_RT = 8;                                           // row tiles per workgroup (128 rows)
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         FLUTE_OPAQUE(a.A); FLUTE_OPAQUE(a.Q); FLUTE_OPAQUE(a.D); FLUTE_OPAQUE(a.S); FLUTE_OPAQUE(a.QM2);
         FLUTE_OPAQUE(a.partial); FLUTE_OPAQUE(a.state); FLUTE_OPAQUE(a.M); FLUTE_OPAQUE(a.N); FLUTE_OPAQUE(a.K);
         FLUTE_OPAQUE(a.G); FLUTE_OPAQUE(a.lg); FLUTE_OPAQUE(a.tiles_m); FLUTE_OPAQUE(a.splitk); FLUTE_OPAQUE(a.k_per_split);
+        FLUTE_OPAQUE(a.pair_lg); FLUTE_OPAQUE(a.pair_c8);
 #undef FLUTE_OPAQUE
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,7 +135,21 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
 
     int tile = blockIdx.x, split = 0;
     if (a.splitk > 1) { split = tile % a.splitk; tile /= a.splitk; }
-    const int tm_idx = tile % a.tiles_m, tn_idx = tile / a.tiles_m;
+    // Block b runs on XCD b % 8 (observed; speed only).  Natural order (row tiles fastest) puts the two row tiles of a column
+    // tile on neighbouring XCDs: each fetches the column tile's weights for itself (FETCH 1.9x the algorithmic bytes at
+    // M = 256, profiles/r04_rocprof).  Here a PAIR of row tiles (2 p, 2 p + 1) x column tile = "pair column" c goes to XCD
+    // c % 8 as that XCD's consecutive blocks: the weights are fetched once per pair, an XCD reads two row tiles of X.
+    int tm_idx, tn_idx;
+    if (a.pair_lg >= 0) {
+        int c, e;
+        if (tile < 2 * a.pair_c8) { const int i = tile >> 3; c = (i >> 1) * 8 + (tile & 7); e = i & 1; }
+        else { c = tile >> 1; e = tile & 1; }                      // the last, incomplete group of eight: natural order
+        tn_idx = c >> a.pair_lg;
+        tm_idx = 2 * (c & ((1 << a.pair_lg) - 1)) + e;
+    } else {
+        tm_idx = tile % a.tiles_m;
+        tn_idx = tile / a.tiles_m;
+    }
     const int m0 = tm_idx * (RT * 16);
     const int unit0 = (tn_idx * NWN + wg) * U;
     const int khalf = a.k_per_split >> 1;

@@ -120,3 +120,29 @@ def test_plan_family6():
     rc, p = _plan(200, 11008, 4096, family=6)
     assert rc == 0 and p.grid == 2 * 86 * p.splitk
     assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=7)[0] != 0   # unknown families are refused
+
+
+def test_xcd_pair_order_is_a_bijection():
+    """qgemm_splitk.h's XCD-aware tile order (splitk == 1): pairs of row tiles x column tile are dealt to the eight XCDs
+    (block b -> XCD b % 8) so that the two row tiles that share a column tile's weights run on ONE XCD; every tile is
+    produced exactly once for any tile grid, the incomplete last group of eight keeps the natural order."""
+    def remap(tile, tiles_m, tiles_n):
+        P = tiles_m // 2
+        if tiles_m < 2 or tiles_m % 2 or (P & (P - 1)):
+            return tile % tiles_m, tile // tiles_m                  # api.hip: pair_lg = -1
+        lg, c8 = P.bit_length() - 1, (P * tiles_n) & ~7
+        if tile < 2 * c8:
+            i = tile >> 3
+            c, e = (i >> 1) * 8 + (tile & 7), i & 1
+        else:
+            c, e = tile >> 1, tile & 1
+        return 2 * (c & ((1 << lg) - 1)) + e, c >> lg
+    for tiles_m in (1, 2, 3, 4, 6, 8, 16):
+        for tiles_n in (1, 2, 7, 8, 9, 32, 86, 112, 224):
+            seen = {remap(t, tiles_m, tiles_n) for t in range(tiles_m * tiles_n)}
+            assert len(seen) == tiles_m * tiles_n and all(0 <= a < tiles_m and 0 <= b < tiles_n for a, b in seen)
+    # M = 256 on 4096 x 11008: the 22 (21) tiles of an XCD are 11-12 whole pairs
+    per = {}
+    for t in range(2 * 86):
+        per.setdefault(t % 8, []).append(remap(t, 2, 86))
+    assert all(len({tn for _, tn in v}) <= len(v) // 2 + 1 for v in per.values())
