@@ -329,54 +329,60 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     const int g = 1 << lg, G = K >> lg;
     if (G % 8 || N % 128 || K % 128) return FLUTE_ERR_SHAPE;
     if ((size_t)(M + 128) * K * 2 >= (size_t)0xfffffff0u || (size_t)N * G * 2 >= (size_t)0xfffffff0u) return FLUTE_ERR_SHAPE;
-    const long tiles = (long)ceil_div(M, 128) * (N / 128);
-    if (tiles > kXwgMaxTiles) return FLUTE_ERR_SHAPE;
     const int align = 2 * std::max(64, g);
-    auto legal = [&](int sk) {
+    // Row tiles per workgroup: 8 (128-row tiles) or 4 (64-row tiles: twice the tiles, half the slab per slice, every weight
+    // dequantised by twice as many workgroups); override m_tiles = 8 / 4 fixes it, else both are priced.
+    auto tiles_of = [&](int rt) { return (long)ceil_div(M, rt * 16) * (N / 128); };
+    auto slab_of = [&](int rt) { return (long)rt * 8192; };      // fp32 partial tile in fragment order: 64 / 32 KB
+    auto legal = [&](int sk, int rt) {
         if (sk < 1 || sk > 16 || K % sk || (K / sk) % align) return false;
+        if (tiles_of(rt) > kXwgMaxTiles) return false;
         const int gh = (K / sk / 2) >> lg;                     // groups per K half
         if (gh + ((gh % 8) ? 7 : 0) > 32) return false;
-        if (sk > 1 && ((size_t)sk * tiles * 65536 > slab_room(workspace_bytes) || (size_t)sk * tiles * 65536 >= ((size_t)1 << 31))) return false;   // slabs: 64 KB per tile and slice
+        const size_t slabs = (size_t)sk * tiles_of(rt) * slab_of(rt);
+        if (sk > 1 && (slabs > slab_room(workspace_bytes) || slabs >= ((size_t)1 << 31))) return false;
         return true;
     };
-    // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run6*.jsonl): a round of workgroups costs ~9.5 us of
-    // launch, prologue, K-half exchange and stores + 0.65 .. 0.96 us per 64-k step (the more of the chip is busy the slower:
-    // 30.3 us on 64 CUs, 32.9 on 172, 39.3 on 224, 40.3 on 256 at K = 4096, loader waves); the seam grows with the MB published
-    // write-through (E form at 2 slices ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
-    auto model_us = [&](int sk) {
-        const long wgs = tiles * sk;
+    // us, fitted to tools/splitk_lab.py on MI355X (profiles/r04/splitk_lab_run8*.jsonl, run9*): a round of workgroups costs ~9.5 us
+    // of launch, prologue, K-half exchange, ramp and stores + per 64-k step 0.65 .. 0.96 us (128-row tiles: 30.3 us on 64 CUs,
+    // 32.9 on 172, 39.3 on 224, 40.3 on 256 at K = 4096 - the more of the chip is busy the slower) or 0.44 .. 0.52 us (64-row
+    // tiles: 23.9 us on 128 CUs, 26.5 on 256); the seam grows with the MB published write-through (E form at 2 slices
+    // ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
+    auto model_us = [&](int sk, int rt) {
+        const long wgs = tiles_of(rt) * sk;
         const long rounds = (wgs + num_sms - 1) / num_sms;
         const double fill = std::min(1.0, (double)wgs / num_sms);
-        const double steps = (double)K / sk / 128.0;       // 64-k steps of a K half
-        const double mb = sk == 1 ? 0.0 : (double)wgs * 0.065536 * ((sk == 2 || sk == 4) ? (sk - 1.0) / sk : 1.0);
+        const double steps = (double)K / sk / 128.0;           // 64-k steps of a K half
+        const bool eform = sk == 2 || (sk == 4 && rt == 8);
+        const double mb = sk == 1 ? 0.0 : (double)wgs * (slab_of(rt) * 1e-6) * (eform ? (sk - 1.0) / sk : 1.0);
         const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : 1.5 + 0.5 * mb);
-        return rounds * (9.5 + steps * (0.65 + 0.31 * fill * fill * fill)) + seam;
+        const double step = rt == 8 ? 0.65 + 0.31 * fill * fill * fill : 0.44 + 0.08 * fill * fill * fill;
+        return rounds * (9.5 + steps * step) + seam;
     };
-    int best = 0;
-    double best_us = 0.0;
-    if (ov.splitk > 0) {
-        if (!legal(ov.splitk)) return FLUTE_ERR_SHAPE;
-        best = ov.splitk; best_us = model_us(best);
-    } else {
-        std::vector<std::pair<double, int>> c;
-        for (int sk = 1; sk <= 16; ++sk) if (legal(sk)) c.push_back({model_us(sk), sk});
-        if (c.empty()) return FLUTE_ERR_SHAPE;
-        std::sort(c.begin(), c.end());
-        const size_t pick = std::min((size_t)std::max(0, rank), c.size() - 1);
-        best = c[pick].second; best_us = c[pick].first;
+    struct Cand { double us; int sk, rt; };
+    std::vector<Cand> c;
+    for (int rt : {8, 4}) {
+        if ((ov.m_tiles == 8 || ov.m_tiles == 4) && rt != ov.m_tiles) continue;
+        for (int sk = 1; sk <= 16; ++sk) {
+            if (ov.splitk > 0 && sk != ov.splitk) continue;
+            if (legal(sk, rt)) c.push_back(Cand{model_us(sk, rt), sk, rt});
+        }
     }
-    if (cost_us) *cost_us = best_us;
+    if (c.empty()) return FLUTE_ERR_SHAPE;
+    std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) { return x.us < y.us; });
+    const Cand best = c[std::min((size_t)std::max(0, rank), c.size() - 1)];
+    if (cost_us) *cost_us = best.us;
     memset(p, 0, sizeof(*p));
     p->family = kFamilySplitK;
     // four loader waves beside the eight compute waves (round 4: K = 4096 per workgroup 34.1 -> 30.3 us on 64 CUs, 35.2 -> 32.9 on
     // 172, 41.8 -> 40.3 on 256); override waves = 8: the variant without them
     const int ldw = (ov.waves == 8) ? 0 : 4;
-    p->m_block = 0; p->m_tiles = 8; p->slabs_per_wave = 1; p->waves = 8 + ldw; p->kw = 2;
-    p->splitk = best; p->k_per_split = K / best;
-    p->grid = (unsigned)(tiles * best); p->block = (unsigned)(512 + 64 * ldw);
-    p->lds_bytes = (size_t)splitk_lds_bytes(bits); p->lut_copies = 32;
-    p->splitk_mode = best > 1 ? 1 : 0;
-    p->workspace_needed = best > 1 ? (size_t)best * tiles * 65536 + kXwgFlagBytes : 0;
+    p->m_block = 0; p->m_tiles = best.rt; p->slabs_per_wave = 1; p->waves = 8 + ldw; p->kw = 2;
+    p->splitk = best.sk; p->k_per_split = K / best.sk;
+    p->grid = (unsigned)(tiles_of(best.rt) * best.sk); p->block = (unsigned)(512 + 64 * ldw);
+    p->lds_bytes = (size_t)splitk_lds_bytes(bits, best.rt); p->lut_copies = 32;
+    p->splitk_mode = best.sk > 1 ? 1 : 0;
+    p->workspace_needed = best.sk > 1 ? (size_t)best.sk * tiles_of(best.rt) * slab_of(best.rt) + kXwgFlagBytes : 0;
     return FLUTE_OK;
 }
 
@@ -1086,14 +1092,14 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.state = reinterpret_cast<uint32_t*>(workspace);
         b.partial = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes) : nullptr;
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
-        b.tiles_m = ceil_div(M, 128);
+        b.tiles_m = ceil_div(M, p.m_tiles * 16);
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
         b.pair_lg = -1; b.pair_c8 = 0;
         if (p.splitk == 1 && b.tiles_m >= 2 && b.tiles_m % 2 == 0 && ((b.tiles_m / 2) & (b.tiles_m / 2 - 1)) == 0) {
             b.pair_lg = ilog2(b.tiles_m / 2);
             b.pair_c8 = ((b.tiles_m / 2) * (N / 128)) & ~7;
         }
-        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.waves == 12 ? 4 : 0);
+        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.waves == 12 ? 4 : 0, p.m_tiles);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&b};

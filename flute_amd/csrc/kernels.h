@@ -37,7 +37,7 @@ BlockKernel block_kernel_b3(int dtype, int tile_p, int cfg);
 // split-K block kernel (qgemm_splitk.h): 128 x 128 tiles, K split over workgroups, combined in the launch (xwg.h)
 struct SplitKArgs;
 typedef void (*SplitKKernel)(const SplitKArgs);
-SplitKKernel splitk_kernel(int bits, int dtype, int tile_p, int ldw);   // ldw: loader waves (0 / 4)
+SplitKKernel splitk_kernel(int bits, int dtype, int tile_p, int ldw, int rt);   // ldw: loader waves (0 / 4), rt: row tiles per workgroup (8 / 4)
 // MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw);   // sw: slabs per wave (1, 2)
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);

@@ -48,15 +48,17 @@ struct SplitKArgs {
     int pair_lg, pair_c8;
 };
 
-constexpr int SK_RT = 8;                                           // row tiles per workgroup (128 rows)
-constexpr int SK_STAGE = SK_RT * 2 * 1024;                         // 128 rows x 64 k: 16 pieces of 1 KB
+// RT row tiles per workgroup: 8 (128-row tiles) or - round 4, for outputs whose 128-row tiles leave most of the chip idle
+// (M = 256 on 4096 x 4096: 64 tiles) - 4 (64-row tiles: twice the tiles, half the slab per slice, every weight
+// dequantised by twice as many workgroups)
+__host__ __device__ constexpr int splitk_stage_bytes(int rt) { return rt * 2 * 1024; }     // RT x 16 rows x 64 k: 1-KB pieces
 constexpr int SK_SCALE_WAVE = 2048;                                // four 8-group blocks x 32 columns x 16 B
 // position swizzle of an 8-row x 8-chunk activation piece (rows 8 rh .. 8 rh + 7 of a 16-row tile): the 16 lanes of every
 // ds_read_b128 lane group hit 16 different 16-B slots of the 256-B bank row (as qgemm_tile.h's swz_x; checked for the
 // lane groups of MI355X_MICROARCH.md's LDS table by tests/test_host.py)
 __host__ __device__ constexpr int sk_swz(int row8, int rh) { return (row8 >> 1) | (rh << 2); }
-__host__ __device__ constexpr int splitk_lds_bytes(int bits) {
-    return (128 << (2 * bits)) + 2 * BLK_STAGES * SK_STAGE + 8 * SK_SCALE_WAVE;
+__host__ __device__ constexpr int splitk_lds_bytes(int bits, int rt = 8) {
+    return (128 << (2 * bits)) + 2 * BLK_STAGES * splitk_stage_bytes(rt) + 8 * SK_SCALE_WAVE;
 }
 
 // LDW = 4: four LOADER waves beside the eight compute waves (block of 768 threads).  A loader issues the activation
@@ -71,7 +73,7 @@ template <int N> __device__ __forceinline__ uint32_t lut_word_after(const uint32
     return v;
 }
 
-template <typename T, int TILEP, int BITS = 4, int LDW = 0>
+template <typename T, int TILEP, int BITS = 4, int LDW = 0, int RT = 8>
 __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const SplitKArgs args) {
     using NT = Num<T>;
     static_assert(BITS == 4 || BITS == 2, "3-bit layers: qgemm_block3.h / qgemm_tile.h");
@@ -79,7 +81,11 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     constexpr int U = 32 / J;                                      // units per wave (32 columns)
     constexpr int FPT = 16 / U;                                    // fields per column tile and unit
     constexpr int FB = 2 * BITS;
-    constexpr int RT = SK_RT, NT2 = 2, NWN = 4;
+    static_assert(RT == 8 || RT == 4, "row tiles per workgroup");
+    constexpr int NT2 = 2, NWN = 4;
+    constexpr int HR = RT / 2;                                     // row tiles a wave keeps after the K halves' exchange
+    constexpr int SK_STAGE = splitk_stage_bytes(RT);
+    constexpr int LPR = 8 / HR;                                    // next-half lookups issued behind each of the first HR row tiles
     static_assert(LDW == 0 || LDW == 4, "loader waves");
     constexpr int NTHR = 512 + 64 * LDW;
     constexpr int PPW = LDW ? 0 : RT * 2 / NWN;                    // activation pieces per COMPUTE wave and step (4; none with loaders)
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     uint32_t x_vo[PPW ? PPW : 1];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int rt = wg * 2 + (i >> 1), rh = i & 1;
+        const int rt = (wg * PPW + i) >> 1, rh = (wg * PPW + i) & 1;
         x_vo[i] = (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ sk_swz(row8, rh)) * 8)) * 2);
     }
     const uint32_t x_grp = (uint32_t)X_BASE + (uint32_t)kh * (BLK_STAGES * SK_STAGE);      // this K half's three stages
@@ -332,11 +338,18 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         uint32_t (&vv)[8] = v[set];                                // (references: a generic lambda captures no variable it only meets as an asm operand)
         u32x4_t (&aa)[RT] = af[set];
         uint32_t (&ss)[NT2] = scn[set];
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]),
-                       "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(aa[4]), "+v"(aa[5]), "+v"(aa[6]), "+v"(aa[7]),
-                       "+v"(ss[0]), "+v"(ss[1])
-                     : : "memory");
+        if constexpr (RT == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]),
+                           "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(aa[4 % RT]), "+v"(aa[5 % RT]), "+v"(aa[6 % RT]), "+v"(aa[7 % RT]),
+                           "+v"(ss[0]), "+v"(ss[1])
+                         : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]),
+                           "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(ss[0]), "+v"(ss[1])
+                         : : "memory");
+        }
     };
 
     auto half = [&](auto slot_tag, auto h_tag, int t) {
@@ -370,14 +383,15 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
                 if constexpr (dbg & 4) acc[R][c][0] += __builtin_bit_cast(float, bf[c][0] ^ af[h][R][0]);
                 else acc[R][c] = Mfma<T>::run(bf[c], af[h][R], acc[R][c]);
             }
-            // the next half step's operands: two fragments and two lookups behind each of the first four row tiles
-            if constexpr (R < RT / 2) {
+            // the next half step's operands: two fragments and 8 / HR lookups behind each of the first HR row tiles
+            if constexpr (R < HR) {
                 if constexpr (!(dbg & 16)) {
                     frag(nxt_t{}, std::integral_constant<int, nslot>{}, nxt_t{}, std::integral_constant<int, 2 * R>{});
                     frag(nxt_t{}, std::integral_constant<int, nslot>{}, nxt_t{}, std::integral_constant<int, 2 * R + 1>{});
                 }
-                lookup(nxt_t{}, qw, std::integral_constant<int, 2 * R>{});
-                lookup(nxt_t{}, qw, std::integral_constant<int, 2 * R + 1>{});
+                [&]<int... L>(std::integer_sequence<int, L...>) {
+                    (lookup(nxt_t{}, qw, std::integral_constant<int, R * LPR + L>{}), ...);
+                }(std::make_integer_sequence<int, LPR>{});
             }
             // batch t+2 behind the last BATCH row tiles of half step 0, one request each
             if constexpr (h == 0 && R >= RT - BATCH)
@@ -420,36 +434,36 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : : "memory");
 
     FLUTE_SKSTAMP(2);
-    // ---- epilogue 1: the K halves swap half of their row tiles through LDS (K half 0 keeps row tiles 0..3, K half 1
-    // keeps 4..7); own[i][t] = row tile 4 kh + i over the workgroup's whole K range ----
-    f32x4_t own[4][NT2];
+    // ---- epilogue 1: the K halves swap half of their row tiles through LDS (K half 0 keeps row tiles 0..HR-1, K half 1
+    // keeps HR..RT-1); own[i][t] = row tile HR kh + i over the workgroup's whole K range ----
+    f32x4_t own[HR][NT2];
     {
         __syncthreads();                                           // every wave is done with the stages
         float4* xb = reinterpret_cast<float4*>(smem + X_BASE);     // [wave][4 row tiles][2 column tiles][64 lanes] x 16 B = 64 KB
-        auto put = [&](int i, int t, const f32x4_t s) { xb[((wave * 4 + i) * NT2 + t) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]); };
-        auto get = [&](int i, int t) { const float4 p = xb[(((wave ^ 4) * 4 + i) * NT2 + t) * 64 + lane]; return f32x4_t{p.x, p.y, p.z, p.w}; };
+        auto put = [&](int i, int t, const f32x4_t s) { xb[((wave * HR + i) * NT2 + t) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]); };
+        auto get = [&](int i, int t) { const float4 p = xb[(((wave ^ 4) * HR + i) * NT2 + t) * 64 + lane]; return f32x4_t{p.x, p.y, p.z, p.w}; };
         if (kh == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) put(i, t, acc[4 + i][t]);
+                for (int t = 0; t < NT2; ++t) put(i, t, acc[HR + i][t]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) put(i, t, acc[i][t]);
         }
         __syncthreads();
         if (kh == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) own[i][t] = acc[i][t] + get(i, t);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) own[i][t] = get(i, t) + acc[4 + i][t];       // K half 0 first in both waves: one order
+                for (int t = 0; t < NT2; ++t) own[i][t] = get(i, t) + acc[HR + i][t];       // K half 0 first in both waves: one order
         }
     }
 
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     uint32_t col[NT2];
 #pragma unroll
     for (int t = 0; t < NT2; ++t) col[t] = (uint32_t)(unit_col0<BITS, TILEP>(c_unit) + ((4 * q4) / U + FPT * t) * TILEP);
-    const int row_base = m0 + kh * 64 + r16;                       // + 16 i
+    const int row_base = m0 + kh * (HR * 16) + r16;                // + 16 i
     auto store_d = [&](int i, int t, const f32x4_t o4) {
         const int row = row_base + 16 * i;
         if (row < a.M) {
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     };
     if (a.splitk == 1 || (dbg & 128)) {                             // (ablation 128: every slice stores its partial as the result - the seam's price)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < HR; ++i)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) store_d(i, t, own[i][t]);
         FLUTE_SKSTAMP_FLUSH();
@@ -484,22 +498,23 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
     // place (the reference's BlockStripedReduce does the same, tile_scheduler_utils.hpp:80-83).  The first version kept the
     // slabs as [M][N] images: 32-B runs per row, write-through one fabric write each - 10 us of seam (profiles/r04).
     const uint32_t ntiles = gridDim.x / (uint32_t)a.splitk;
-    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(a.partial, (uint32_t)a.splitk * ntiles * 65536u);
-    const uint32_t slab_lane = (uint32_t)tile * 65536u + (uint32_t)wave * 8192u + (uint32_t)lane * 16u;
+    constexpr uint32_t TILE_SLAB = 8u * HR * NT2 * 1024u;            // 8 waves x HR x 2 fragments of 1 KB: 64 KB (RT = 8) / 32 KB
+    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(a.partial, (uint32_t)a.splitk * ntiles * TILE_SLAB);
+    const uint32_t slab_lane = (uint32_t)tile * TILE_SLAB + (uint32_t)wave * (HR * NT2 * 1024u) + (uint32_t)lane * 16u;
     auto slab_off = [&](int slice, int i, int t) {
-        return (uint32_t)slice * (ntiles * 65536u) + slab_lane + (uint32_t)(i * NT2 + t) * 1024u;
+        return (uint32_t)slice * (ntiles * TILE_SLAB) + slab_lane + (uint32_t)(i * NT2 + t) * 1024u;
     };
     xwg_word* st = xwg_state(a.state + 2 * tile);
     const uint32_t bcast = 0;                                      // LDS dword 0 (the pair table is dead)
     const int nsl = a.splitk;
 
-    // E form for NSH = 2, 4 shares (share q = row tiles q, q + NSH, ... of every wave), PER = 4 / NSH row tiles per share
+    // E form for NSH = 2, 4 shares (share q = row tiles q, q + NSH, ... of every wave), PER = HR / NSH row tiles per share
     auto e_form = [&]<int NSH>(std::integral_constant<int, NSH>) {
-        constexpr int PER = 4 / NSH;
+        constexpr int PER = HR / NSH;
         const int me = split;
         f32x4_t mine[PER][NT2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < HR; ++i) {
             if (i % NSH == me) {                                   // wave-uniform
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) mine[i / NSH][t] = own[i][t];
@@ -564,15 +579,15 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         }
     };
 
-    if (nsl == 4) {
-        e_form(std::integral_constant<int, 4>{});
+    if (nsl == 4 && HR % 4 == 0) {
+        if constexpr (HR % 4 == 0) e_form(std::integral_constant<int, 4>{});
     } else if (nsl == 2) {
         e_form(std::integral_constant<int, 2>{});
     } else {
         // L form: every slice publishes its whole partial; the last arriver sums ALL slices in ascending order (its own
         // from the slab as well: one order whoever is last)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < HR; ++i)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) xwg_store(own[i][t], slab, slab_off(split, i, t));
         FLUTE_SKSTAMP(4);
@@ -582,24 +597,24 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         stamp[9] = before;
 #endif
         if (before == (uint32_t)(nsl - 1)) {
-            f32x4_t s[4][NT2];
+            f32x4_t s[HR][NT2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) s[i][t] = xwg_load(slab, slab_off(0, i, t));
             for (int s2 = 1; s2 < nsl; ++s2) {
-                f32x4_t ld[4][NT2];
+                f32x4_t ld[HR][NT2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < HR; ++i)
 #pragma unroll
                     for (int t = 0; t < NT2; ++t) ld[i][t] = xwg_load(slab, slab_off(s2, i, t));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < HR; ++i)
 #pragma unroll
                     for (int t = 0; t < NT2; ++t) s[i][t] += ld[i][t];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) store_d(i, t, s[i][t]);
             xwg_reset(st, tid);

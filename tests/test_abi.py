@@ -266,12 +266,14 @@ def test_plan_invariants_over_random_shapes():
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
             assert bits != 3 or p.m_block == 1, what
         elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
-            tiles = -(-M // 128) * (N // 128)
+            assert p.m_tiles in (8, 4), what                      # 128- / 64-row tiles
+            tiles = -(-M // (p.m_tiles * 16)) * (N // 128)
             assert bits in (2, 4) and M >= 128 and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
             assert p.k_per_split * p.splitk == K and p.k_per_split % (2 * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
             gh = p.k_per_split // 2 // g
             assert gh + (7 if gh % 8 else 0) <= 32, what
-            assert p.splitk_mode == (1 if p.splitk > 1 else 0) and p.workspace_needed == (p.splitk * tiles * 65536 + 65536 if p.splitk > 1 else 0), what
+            assert p.splitk_mode == (1 if p.splitk > 1 else 0) and p.workspace_needed == (p.splitk * tiles * p.m_tiles * 8192 + 65536 if p.splitk > 1 else 0), what
+            assert p.lds_bytes == (128 << (2 * bits)) + 6 * p.m_tiles * 2048 + 16384, what
         else:                                                     # block kernels
             assert p.family == 3 and p.m_block in (4, 5, 9, 10, 12) and p.block == 512, what
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what

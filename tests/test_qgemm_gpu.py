@@ -508,23 +508,24 @@ def test_splitk_block_kernel(env):
             ref = X.float() @ What
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
             ran = set()
-            for sk in (1, 2, 3, 4, 6, 8, 16):
-                ovr = dev.Overrides(family=6, splitk=sk)
+            for sk, rt in [(sk, rt) for sk in (1, 2, 3, 4, 6, 8, 16) for rt in (8, 4)]:      # 128- and 64-row tiles
+                ovr = dev.Overrides(family=6, splitk=sk, m_tiles=rt)
                 try:
                     plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
                 except RuntimeError:
                     continue                                      # not a legal split of this K (qgemm_splitk.h's host contract)
-                assert plan["family"] == 6 and plan["splitk"] == sk and plan["grid"] == -(-M // 128) * (N // 128) * sk and plan["waves"] == 12
+                assert plan["family"] == 6 and plan["splitk"] == sk and plan["m_tiles"] == rt and plan["waves"] == 12
+                assert plan["grid"] == -(-M // (16 * rt)) * (N // 128) * sk
                 ran.add(sk)
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
                 out2 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
-                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, sk)
-                assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk)
-                assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk)
-                assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk)
+                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, sk, rt)
+                assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk, rt)
+                assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk, rt)
+                assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk, rt)
                 if M in (130, 700) and sk in (1, 2, 3):              # the variant without loader waves: the same numbers
-                    o8 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=6, splitk=sk, waves=8))
+                    o8 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=6, splitk=sk, m_tiles=rt, waves=8))
                     assert torch.equal(o8, out), (bits, tile_p, g, dtype, K, N, M, sk)
             assert 1 in ran or g == 32 and K > 2048, (K, g, ran)
             assert len(ran) >= 3, (K, g, ran)
@@ -553,12 +554,13 @@ def test_splitk_seam_under_load(env):
     hand-off under uneven load, consumer caches warm, every word)."""
     import bench
     from flute_amd import dev
-    for (M, N, K, sk, fam, dtype) in ((256, 4096, 4096, 4, 6, torch.float16), (200, 2048, 4096, 8, 6, torch.bfloat16),
-                                      (256, 2048, 8192, 2, 6, torch.float16), (16, 4096, 4096, 4, 5, torch.float16),
-                                      (9, 2048, 8192, 8, 5, torch.bfloat16)):
+    for (M, N, K, sk, fam, dtype, rt) in ((256, 4096, 4096, 4, 6, torch.float16, 8), (200, 2048, 4096, 8, 6, torch.bfloat16, 8),
+                                          (256, 2048, 8192, 2, 6, torch.float16, 8), (256, 4096, 4096, 2, 6, torch.float16, 4),
+                                          (200, 2048, 4096, 4, 6, torch.bfloat16, 4), (16, 4096, 4096, 4, 5, torch.float16, -1),
+                                          (9, 2048, 8192, 8, 5, torch.bfloat16, -1)):
         lay = bench.Layer(M, N, K, 4, 64, dtype, env.dev, 3)
         lay.template_id = template_ids_for(env.fa, 4, 32)[0]
-        lay.ovr = dev.Overrides(family=fam, splitk=sk)
+        lay.ovr = dev.Overrides(family=fam, splitk=sk, m_tiles=rt)
         plan = dev.get_plan(M, N, K, 4, 64, lay.template_id, env.num_sms, dtype, lay.ovr)
         assert plan["family"] == fam and plan["splitk"] == sk and plan["splitk_mode"] == 1, plan
         first = [lay.step(c).clone() for c in range(3)]

@@ -100,11 +100,13 @@ def test_plan_family6():
     assert rc == 0 and p.family == 6 and p.block == 768 and p.waves == 12 and p.kw == 2      # 8 compute + 4 loader waves
     rc8, p8 = _plan(256, 4096, 4096, family=6, waves=8)
     assert rc8 == 0 and p8.block == 512 and p8.waves == 8                                    # the variant without loader waves
-    assert p.splitk == 2 and p.k_per_split == 2048 and p.grid == 128 and p.splitk_mode == 1     # (measured: 24.1 us, four slices 25.1)
-    assert p.workspace_needed == 2 * 64 * 65536 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384   # 64 KB per tile and slice
-    assert _plan(256, 4096, 4096, family=6, splitk=16)[0] != 0         # 64 MiB of slabs + the state words: one page too many
+    assert p.m_tiles == 4 and p.splitk == 2 and p.k_per_split == 2048 and p.grid == 256 and p.splitk_mode == 1     # 64-row tiles x two slices (measured 19.3 us; 128-row tiles 22.0)
+    assert p.workspace_needed == 2 * 128 * 32768 + (64 << 10) and p.lds_bytes == 32768 + 49152 + 16384   # 32 KB per 64-row tile and slice
+    rc, p = _plan(256, 4096, 4096, family=6, m_tiles=8)
+    assert rc == 0 and p.m_tiles == 8 and p.splitk == 2 and p.grid == 128 and p.workspace_needed == 2 * 64 * 65536 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384
+    assert _plan(256, 4096, 4096, family=6, splitk=16, m_tiles=8)[0] != 0     # 64 MiB of slabs + the state words: one page too many
     for sk in (1, 2, 4, 8, 16):
-        rc, p = _plan(256, 4096, 4096, family=6, splitk=sk, ws=128 << 20)
+        rc, p = _plan(256, 4096, 4096, family=6, splitk=sk, m_tiles=8, ws=128 << 20)
         assert rc == 0 and p.splitk == sk and p.grid == 64 * sk and p.k_per_split * sk == 4096
         assert p.splitk_mode == (1 if sk > 1 else 0)
     assert _plan(256, 4096, 4096, family=6, splitk=3)[0] != 0          # 4096 / 3
@@ -117,7 +119,7 @@ def test_plan_family6():
     rc, p = _plan(256, 4096, 4096, g=256, family=6, splitk=8)           # K half = one 256-wide group
     assert rc == 0 and p.k_per_split == 512
     assert _plan(256, 4096, 4096, g=256, family=6, splitk=16)[0] != 0
-    rc, p = _plan(200, 11008, 4096, family=6)
+    rc, p = _plan(200, 11008, 4096, family=6, m_tiles=8)
     assert rc == 0 and p.grid == 2 * 86 * p.splitk
     assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=7)[0] != 0   # unknown families are refused
 

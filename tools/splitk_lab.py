@@ -334,7 +334,73 @@ def time_had():
             emit({"kind": "time_had", "M": M, "N": N, "K": K, "qgemm_us": us[0], "qgemm_hadamard_us": us[512], "rotation_us": round(us[512] - us[0], 2)})
 
 
+def check_rt4():
+    """64-row tiles (override m_tiles = 4) on a subset of check()'s cases."""
+    nfail = 0
+    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
+                                           (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (4, 32, 32, f16, 1024, 256)]:
+        torch.manual_seed(K + N)
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(2 ** bits, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = tid_of(bits, tile_p)
+        Q = utils.pack(W, bits, [tid], num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        tol = 1e-3 if dtype == f16 else 8e-3
+        for M in (1, 60, 64, 130, 256, 700):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for sk in (1, 2, 3, 4, 8):
+                for waves in (-1, 8):
+                    rec = {"kind": "check_rt4", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "splitk": sk, "waves": waves}
+                    try:
+                        ovr = dev.Overrides(family=6, splitk=sk, m_tiles=4, waves=waves)
+                        try:
+                            pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
+                        except RuntimeError:
+                            continue
+                        assert pl["m_tiles"] == 4 and pl["grid"] == -(-M // 64) * (N // 128) * sk, pl
+                        o = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                        o1 = dev.qgemm_planned(E, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                        o2 = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                        torch.cuda.synchronize()
+                        err = ((o.float() - ref).norm() / ref.norm()).item()
+                        rec.update(err=err, onehot_exact=bool(torch.equal(o1, What[ks])), repeat_identical=bool(torch.equal(o, o2)), state_clean=state_clean())
+                        rec["ok"] = bool(err < tol and rec["onehot_exact"] and rec["repeat_identical"] and rec["state_clean"])
+                        if not rec["state_clean"]:
+                            ws[:65536].zero_()
+                    except Exception as ex:  # noqa: BLE001
+                        rec.update(ok=False, error=str(ex)[:300])
+                    if not rec["ok"]:
+                        nfail += 1
+                    emit(rec)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    emit({"kind": "check_rt4_summary", "failed": nfail})
+    return nfail
+
+
+def time_rt4():
+    for (M, N, K) in ((256, 4096, 4096), (128, 4096, 4096), (512, 4096, 4096), (128, 11008, 4096), (256, 8192, 4096), (64, 4096, 4096), (256, 6144, 4096)):
+        time_one(M, N, K, 4, f16, None)
+        for sk in (1, 2, 4):
+            for rt in (8, 4):
+                try:
+                    dev.get_plan(M, N, K, 4, 64, tid_of(4, 32), num_sms, f16, dev.Overrides(family=6, splitk=sk, m_tiles=rt))
+                except RuntimeError:
+                    continue
+                time_one(M, N, K, 4, f16, dict(family=6, splitk=sk, m_tiles=rt))
+
+
 rc = 0
+if "check_rt4" in what:
+    rc |= check_rt4()
+if "time_rt4" in what:
+    time_rt4()
 if "time_had" in what:
     time_had()
 if "check_ldw" in what:
