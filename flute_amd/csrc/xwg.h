@@ -35,7 +35,10 @@ namespace flute_amd {
 
 constexpr size_t kXwgFlagBytes = 64 * 1024;
 constexpr int kXwgMaxTiles = (int)(kXwgFlagBytes / 8);
-constexpr unsigned kXwgSpinLimit = 4096;          // polls of ~0.3-1 us each before an owner gives its share up
+#ifndef FLUTE_XWG_SPIN_LIMIT
+#define FLUTE_XWG_SPIN_LIMIT 4096     // development builds set 0 / 1: every owner that is not last gives up at once - the abandon / sweep path under test
+#endif
+constexpr unsigned kXwgSpinLimit = FLUTE_XWG_SPIN_LIMIT;   // polls of ~0.3-1 us each before an owner gives its share up
 
 typedef uint32_t xwg_u32x4 __attribute__((ext_vector_type(4)));
 // state words are addressed as GLOBAL memory (global_atomic_*, not flat_*: MI355X_MICROARCH.md, Guideline 16)
@@ -98,7 +101,7 @@ __device__ __forceinline__ uint32_t xwg_sweep(xwg_word* st, uint32_t nsl, uint32
     if (tid == 0) {
         const uint32_t want = ((1u << nsl) - 1u) & ~(1u << mine);
         uint32_t w1 = 0;
-        for (unsigned spin = 0; spin < (kXwgSpinLimit << 4); ++spin) {   // (a bound for form's sake: every owner's poll is bounded)
+        for (unsigned spin = 0; spin < ((kXwgSpinLimit > 4096u ? kXwgSpinLimit : 4096u) << 4); ++spin) {   // (a bound for form's sake: every owner's poll is bounded)
             w1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((((w1 | (w1 >> 16)) & want) == want)) break;
             __builtin_amdgcn_s_sleep(8);

@@ -8,6 +8,11 @@ cd "$(dirname "$0")/../flute_amd/csrc"
 make -j16 >/dev/null
 for n in "$@"; do
   mkdir -p build_abl
+  if [ "$n" = spin0 ]; then   # not an ablation: kXwgSpinLimit = 0, every owner that is not last abandons its share (xwg.h's fallback path)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -DFLUTE_XWG_SPIN_LIMIT=0 -c inst_splitk.hip -o build_abl/inst_splitk_$n.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -mllvm -amdgpu-kernarg-preload-count=14 -DFLUTE_XWG_SPIN_LIMIT=0 -c inst_oneshot_skinny_b4.hip -o build_abl/inst_skinny_$n.o &
+    continue
+  fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -DFLUTE_SK_ABLATE=$n -c inst_splitk.hip -o build_abl/inst_splitk_$n.o &
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -mllvm -amdgpu-kernarg-preload-count=14 -DFLUTE_SK_ABLATE=$n -c inst_oneshot_skinny_b4.hip -o build_abl/inst_skinny_$n.o &
 done
