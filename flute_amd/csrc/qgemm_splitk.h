@@ -1,29 +1,35 @@
-// Split-K block kernel (round 4): 128 x 128 output tiles, K split over workgroups, partial tiles combined INSIDE the launch.
+// Split-K block kernel (round 4): 128 (or 64) x 128 output tiles, K split over workgroups, partial tiles combined INSIDE the launch.
 //
-// The chip-filling schedule for 128 <= M <= ~1024 on 4096-wide layers that rounds 2 and 3 lacked: the reference's Stream-K
-// hands every CTA an equal share of tiles_M x tiles_N x tiles_K for any M (flute/csrc/tile_scheduler_utils.hpp:460-481,
-// fix-up :58-211, main loop qgemm_kernel.hpp:617-712).  Here M = 256 on 4096 x 4096 is 2 x 32 tiles of 128 x 128, each
-// cut four ways in K: 256 workgroups, one per CU, 1024 k each; the four partial tiles of an output tile meet through the
-// workspace with write-through stores and one arrival word (xwg.h) - no second launch, no release fence.
+// The chip-filling schedule for 128 <= M <= ~1024 that rounds 2 and 3 lacked: the reference's Stream-K hands every CTA an equal
+// share of tiles_M x tiles_N x tiles_K for any M (flute/csrc/tile_scheduler_utils.hpp:460-481, fix-up :58-211, main loop
+// qgemm_kernel.hpp:617-712).  Here the output is cut into tiles of RT x 16 rows x 128 columns, each cut `splitk` ways in K -
+// one workgroup per (tile, slice); the partial tiles of an output tile meet through the workspace with write-through
+// stores and one arrival word (xwg.h): no second launch, no release fence.  M = 256 x 4096 x 11008: 172 tiles x 1 slice;
+// M = 1024 x 4096^2: 256 tiles; M = 256 x 4096^2: 128 tiles of 64 rows x 2 slices.
 //
-// Workgroup = 8 waves = 4 column groups (32 columns = two MFMA column tiles each, as qgemm_block2.h) x 2 K halves: the
-// waves of K half g run the block2 pipeline on the contiguous half [g kps / 2, (g + 1) kps / 2) of the workgroup's K
-// range with their own three 64-k activation stages; every weight of the workgroup's range is dequantised exactly once
-// (8 lookups + 8 multiplies per 16 MFMAs of a 32-k half step), a wave holds 8 row tiles x 2 column tiles = 64
-// accumulator registers.  Differences from qgemm_block2.h, all aimed at the short (8-step) main loop of this regime:
-//   * activation pieces are 8 rows x 128 B - WHOLE cache lines (a request is priced per line it touches:
-//     tools/stamps_skinny.py; block2's pieces are 16 rows x 64 B); fragment swizzle sk_swz (= qgemm_tile.h's swz_x);
+// Workgroup = 8 compute waves = 4 column groups (32 columns = two MFMA column tiles each, as qgemm_block2.h) x 2 K halves
+// (+ LDW = 4 loader waves): the waves of K half g run the block2 pipeline on the contiguous half [g kps / 2, (g + 1) kps / 2)
+// of the workgroup's K range with their own three 64-k activation stages; every weight of the workgroup's range is
+// dequantised exactly once (8 lookups + 8 multiplies per RT x 2 MFMAs of a 32-k half step), a wave holds RT row tiles x 2
+// column tiles of accumulators.  What differs from qgemm_block2.h (each step measured: DESIGN.md 3.2d, profiles/r04/):
+//   * activation pieces are 8 rows x 128 B - WHOLE cache lines (a request is priced per line it touches); fragment
+//     swizzle sk_swz (= qgemm_tile.h's swz_x);
 //   * the wave's scales for its whole K half are fetched once, by the prologue (<= 32 groups x 32 columns = 2 KB per
 //     wave): no scale request - and no sink request - per step;
-//   * a step's requests are 4 activation pieces + ONE weight piece (whole lines too; the half step a lane lacks comes
-//     from its partner lane by DPP) per wave, riding between the MFMAs of half step 0.
-// Epilogue: (1) the two K halves exchange half of their row tiles through LDS (every wave ends with 4 row tiles x 2 column
-// tiles of the workgroup's K range), (2) splitk > 1: the E form of xwg.h when splitk is 2 or 4 (slice s owns row tile
-// s, s + nsh, ... of every wave), the L form otherwise; sums are taken in a fixed order (owner first, then the other slices
-// ascending; L: all slices ascending), so the result does not depend on arrival order.
+//   * ONE whole-line weight request per compute wave and step (the half step a lane lacks comes from its partner lane
+//     by DPP row_ror:8);
+//   * the operand registers are double-buffered: the next half step's LDS reads are issued behind the first RT / 2 row
+//     tiles' MFMAs;
+//   * the loader waves issue every activation piece (RT per loader and step, both K halves); without them (LDW = 0) a
+//     compute wave issues RT / 2 pieces per step between the MFMAs of half step 0;
+//   * XCD-aware tile order when K is not split: the row-tile pairs that share a column tile's weights run on one XCD.
+// Epilogue: (1) the two K halves exchange half of their row tiles through LDS (every wave ends with RT / 2 row tiles x 2
+// column tiles of the workgroup's K range), (2) splitk > 1: the E form of xwg.h when splitk is 2 (or 4 with RT = 8: slice s
+// owns row tiles s, s + nsh, ... of every wave), the L form otherwise; sums are taken in a fixed order (owner first, then
+// the other slices ascending; L: all slices ascending), so the result does not depend on arrival order.
 // Arithmetic contract as qgemm_block2.h: w^ = round_T(lut * s) (packbits_utils.hpp:139), fp32 accumulation, one rounding.
 // Host contract (api.hip, plan_splitk): 2 or 4 bits, G % 8 == 0, K % k_per_split == 0, k_per_split % (2 * max(64, g)) == 0,
-// at most 32 scale groups (+ alignment slack: four 8-group blocks) per K half, splitk * tiles * 64 KB of slabs < 2^31.
+// at most 32 scale groups (+ alignment slack: four 8-group blocks) per K half, splitk * tiles * RT * 8 KB of slabs < 2^31.
 #pragma once
 #include <utility>
 

@@ -70,8 +70,9 @@ typedef struct flute_plan {
                             (4-bit, enough 128/256 x 256 output blocks to fill the chip), 5 = skinny MFMA kernel
                             (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
                             slabs fill 55..100 % of the CUs; weights and activations straight to registers),
-                            6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, 128 x 128 output tiles x splitk K
-                            slices, one workgroup each, partial tiles combined inside the launch) */
+                            6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, m_tiles x 16 rows (128 or 64) x 128 columns
+                            output tiles x splitk K slices, one workgroup of 8 compute + 4 loader waves each, partial tiles
+                            combined inside the launch) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
@@ -99,8 +100,8 @@ typedef struct flute_plan {
 /* Per-call launch-plan overrides for the offline tuner, the sweeps and the tests; every field -1 (or a
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
  *   family          5 skinny MFMA kernel (4-bit, M <= 16; waves 4 / 8 picks the in-workgroup K split);
- *                   6 split-K block kernel (splitk picks the K slices per 128 x 128 tile; 1 = none; waves 8 = without the
- *                   four loader waves);
+ *                   6 split-K block kernel (splitk picks the K slices per tile; 1 = none; m_tiles 8 / 4: 128- / 64-row
+ *                   tiles; waves 8 = without the four loader waves);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
  *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)
