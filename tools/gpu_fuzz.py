@@ -67,6 +67,11 @@ for case in range(ncases):
     X = (torch.randn(M, K, device=dev) / 100).to(dtype)
     ref = X.float() @ What
     tag = f"case {case}: b{bits} tid{tid} tp{tile_p} g{g} {str(dtype)[6:]} K{K} N{N} M{M}"
+    if ovr is not None:                                            # a forced plan that does not exist for this draw: skipped, not failed
+        try:
+            fdev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
+        except RuntimeError:
+            continue
     try:
         out = run(X, Q, S, table, table2, bits, g, tid)
         torch.cuda.synchronize()
