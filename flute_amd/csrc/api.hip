@@ -780,6 +780,13 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (splitk == 1) kps = K;
         p->m_block = R; p->m_tiles = mt; p->slabs_per_wave = sw; p->waves = nw; p->kw = kw; p->splitk = splitk;
         p->k_per_split = kps;
+        // round 4: the K slices of a (slab group, row tile) meet inside the launch (xwg.h, L form) while the slabs are small -
+        // the reduce launch it replaces costs >= 2 us; beyond 4 MB of slabs the all-CU reduce pass reads them faster than the
+        // last arrivers would
+#ifndef FLUTE_TILE_INLAUNCH_MAX
+#define FLUTE_TILE_INLAUNCH_MAX (4 << 20)     // bytes of slabs; development builds set 0 to time the two-launch form
+#endif
+        if (splitk > 1 && wgs <= kXwgMaxTiles && (size_t)splitk * M * N * 4 <= (size_t)FLUTE_TILE_INLAUNCH_MAX) p->splitk_mode = 1;
         p->grid = (unsigned)(wgs * splitk);
         p->block = (unsigned)(nw * 64);
         p->lds_bytes = (size_t)tile_geom(bits, R, mt, sw, nw, kMaxLds).total;
@@ -1149,6 +1156,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     a.lut_shift = 0;
     a.lds_budget = kMaxLds;
     a.lkw = ilog2(p.kw);
+    a.state = (p.splitk > 1 && p.splitk_mode == 1) ? reinterpret_cast<uint32_t*>(workspace) : nullptr;
     a.had_log = had_log;
     a.had_scale = had_scale;
     for (int i = 0; i < 10; ++i) a.geo[i] = 0;
@@ -1171,7 +1179,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         (void)hipGetLastError();
         return FLUTE_ERR_LAUNCH;
     }
-    if (p.splitk > 1)
+    if (p.splitk > 1 && p.splitk_mode == 0)
         return splitk_reduce_dispatch(dtype, a.partial, D, (size_t)M * N, p.splitk, st);
     return FLUTE_OK;
 }

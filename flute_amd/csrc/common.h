@@ -145,6 +145,9 @@ struct QGemmArgs {
     // unit groups / workgroups (quotient, remainder); MFMA: depth, scale_bytes, slot_bytes,
     // wave_bytes, row-tile count, XCD-aware block order flag
     int geo[10];
+    // grid-level K split combined INSIDE the launch (xwg.h, L form; qgemm_tile.h since round 4): two state words per
+    // (slab group, row tile) of the grid; nullptr: fp32 slabs + the reduce launch
+    uint32_t* state;
 };
 
 // ---- LDS access by absolute byte address -----------------------------------------

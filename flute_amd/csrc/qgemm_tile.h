@@ -32,6 +32,7 @@
 #pragma once
 #include "common.h"
 #include "mfma.h"
+#include "xwg.h"
 
 namespace flute_amd {
 
@@ -575,6 +576,8 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
     // ---- epilogue: the kw partial tiles of a slab are summed through LDS by ALL its waves
     // (tile tt of the slab by wave tt % kw), then stored 8 B (16 B for split-K partials) per lane ----
     const int c0 = q4 * 4;                                           // first of this lane's 4 columns inside a tile
+    const bool inl = a.splitk > 1 && a.state != nullptr;
+    const __amdgpu_buffer_rsrc_t slabs = xwg_rsrc(a.partial, inl ? (uint32_t)((size_t)a.splitk * a.M * a.N * 4) : 0u);
     auto store_tile = [&](int mt, int i, const f32x4_t v) {
         const int row = m0 + mt * 16 + r16;
         if (row >= a.M) return;
@@ -584,9 +587,32 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
             o.x = (uint32_t)NT::from_float(v[0]) | ((uint32_t)NT::from_float(v[1]) << 16);
             o.y = (uint32_t)NT::from_float(v[2]) | ((uint32_t)NT::from_float(v[3]) << 16);
             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col) = o;
+        } else if (inl) {
+            xwg_store(v, slabs, (uint32_t)((((size_t)split * a.M + row) * a.N + col) * 4));     // write-through: combined below, in this launch
         } else {
             *reinterpret_cast<f32x4_t*>(a.partial + ((size_t)split * a.M + row) * a.N + col) = v;
         }
+    };
+    // the same tile of every K slice, summed in ascending slice order (round 4: the last workgroup to arrive at a
+    // (slab group, row tile) does this for the tiles its waves stored - the reference's fix-up, tile_scheduler_utils.hpp:58-211,
+    // without a second launch)
+    auto combine_tile = [&](int mt, int i) {
+        const int row = m0 + mt * 16 + r16;
+        if (row >= a.M) return;
+        const int col = unit_col0<BITS, TILEP>((slab + i / NMFS) * SU + c0 % SU) + ((i % NMFS) * R + c0 / SU) * TILEP;
+        const uint32_t off = (uint32_t)(((size_t)row * a.N + col) * 4), slice = (uint32_t)((size_t)a.M * a.N * 4);
+        f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < a.splitk; s0 += 4) {
+            f32x4_t ld[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ld[j] = xwg_load(slabs, s0 + j < a.splitk ? (uint32_t)(s0 + j) * slice + off : 0xfffffff0u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v += ld[j];                // past the last slice: out of range reads as zero
+        }
+        uint2 o;
+        o.x = (uint32_t)NT::from_float(v[0]) | ((uint32_t)NT::from_float(v[1]) << 16);
+        o.y = (uint32_t)NT::from_float(v[2]) | ((uint32_t)NT::from_float(v[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col) = o;
     };
     if (kw == 1) {
 #pragma unroll
@@ -613,6 +639,26 @@ __global__ __launch_bounds__(512) void qgemm_tile_kernel(const QGemmArgs a) {
                     v += *reinterpret_cast<const f32x4_t*>(smem + ((size_t)((sl * kw + kp) * PASS + tl) * 64 + lane) * 16);
                 store_tile((p0 + tl) / NMF, (p0 + tl) % NMF, v);
             }
+        }
+    }
+    if (inl) {
+        // bid = this workgroup's (slab group, row tile) index: the K slices of it are neighbouring blocks
+        xwg_word* st = xwg_state(a.state + 2 * (size_t)((int)blockIdx.x / a.splitk));
+        const uint32_t before = xwg_arrive(st, 0u, tid);           // (LDS dword 0: the table is dead, the barrier inside retires the epilogue's reads)
+        if (before == (uint32_t)(a.splitk - 1)) {
+            if (kw == 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i) combine_tile(mt, i);
+            } else {
+                constexpr int NT_TILES = MT * NMF;
+                constexpr int PASS = NT_TILES > 16 ? 16 : NT_TILES;
+#pragma unroll
+                for (int p0 = 0; p0 < NT_TILES; p0 += PASS)
+                    for (int tl = kpart; tl < PASS; tl += kw) combine_tile((p0 + tl) / NMF, (p0 + tl) % NMF);
+            }
+            xwg_reset(st, tid);
         }
     }
 #ifdef FLUTE_STAMPS

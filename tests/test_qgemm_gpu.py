@@ -182,6 +182,29 @@ def test_forced_splitk_and_kw_variants(env):
             for one in (0, 1):
                 D = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=0, one_shot=one))
                 assert rel_err(D, ref) < FP16_TOL, (M, "one_shot", one)
+    # the per-wave MFMA kernel's grid split is combined inside the launch while the slabs are small (round 4: csrc/xwg.h, L
+    # form) and by the reduce pass beyond; both forms, every in-workgroup split, one-hot rows exact, repeat-identical, the
+    # state words left clean
+    from flute_amd import dev
+    d = env.dev
+    Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+    for (M, N2, modes) in ((64, N, (1,)), (16, N, (1,)), (3000, N, (0,))):
+        X = (torch.randn(M, K) / 100).to(dtype)
+        ks = torch.randint(0, K, (M,))
+        E = torch.zeros(M, K, dtype=dtype)
+        E[torch.arange(M), ks] = 1
+        ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
+        for kw in (1, 2, 8):
+            for splitk in (2, 3, 4, 8):
+                ovr = dev.Overrides(family=2, kw=kw, splitk=splitk)
+                plan = dev.get_plan(M, N2, K, bits, g, tid, env.num_sms, dtype, ovr)
+                assert plan["family"] == 2 and plan["splitk"] > 1 and plan["splitk_mode"] in modes, plan
+                o = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                o1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                o2 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
+                assert rel_err(o.cpu(), X.float() @ What) < FP16_TOL, (M, kw, splitk)
+                assert torch.equal(o1.cpu(), ref1) and torch.equal(o, o2), (M, kw, splitk)
+                assert int(env.ws[:65536].view(torch.int32).abs().sum().item()) == 0, (M, kw, splitk)
 
 
 def test_decode_plan_shapes(env):
