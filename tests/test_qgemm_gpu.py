@@ -159,8 +159,8 @@ def test_ragged_k_and_odd_shapes(env, bits, tile_p):
 
 def test_forced_splitk_and_kw_variants(env):
     """Every K-split mode of both kernel families gives the same answer: in-workgroup split (kw), grid split
-    (fp32 slabs + reduce pass), any number of waves per workgroup (the decode kernel is not limited to powers
-    of two), both ring depths, and the round-1 decode kernel kept for A/B runs (family 4)."""
+    (fp32 slabs combined inside the launch by the last arriver - csrc/xwg.h - or by the reduce pass), any number of waves
+    per workgroup (the decode kernel is not limited to powers of two), both ring depths."""
     bits, tile_p, g, dtype = 4, 32, 64, torch.float16
     K, N = 4096, 512
     W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=7)
