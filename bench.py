@@ -443,6 +443,8 @@ def main():
         for (tag, m, n, k, b, dt) in (
                 ("W3G64 bf16 M=4096 K=4096 N=4096 prefill", 4096, 4096, 4096, 3, bf16),
                 ("W3G64 bf16 M=1024 K=8192 N=28672 prefill (configs[2] layer)", 1024, 28672, 8192, 3, bf16),
+                ("W3G64 bf16 M=256 K=8192 N=8192 (configs[2] layer; 128-row blocks x 4 K slices)", 256, 8192, 8192, 3, bf16),
+                ("W3G64 bf16 M=1024 K=4096 N=4096 (128-row blocks x 2 K slices)", 1024, 4096, 4096, 3, bf16),
                 ("W2G64 fp16 M=4096 K=4096 N=4096 prefill", 4096, 4096, 4096, 2, dtype)):
             lay = Layer(m, n, k, b, g, dt, device, copies_for(n, k, b), None)
             lay.tune()

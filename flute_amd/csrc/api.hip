@@ -569,14 +569,14 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     }
     // Block-tiled prefill kernels (qgemm_block2.h: 256 x 256 or 128 x 256 blocks, a wave owns all rows and 32
     // columns, 4- and 2-bit layers; qgemm_block3.h: the same for 3 bits, 128-row blocks); scale rows in
-    // whole 16-B granules.  No K split (the fp32 partial slabs would cost more than the kernel), so what decides is
+    // whole 16-B granules.  No K split for 2 / 4 bits (qgemm_splitk.h serves that regime; 3 bits: priced below), so what decides is
     // how many blocks the output has.  Cost model fitted to tools/block_lab.py (MI355X, K = 4096; us per block,
     // running alone / with the whole chip busy - the chip clocks down under a full MFMA load):
     //   256-row block fp16 100 / 126, bf16 104 / 129;  128-row block fp16 72 / 81, bf16 80 / 89 (round 2);
     //   round 4 (2- / 4-bit blocks: whole-line activation pieces, one whole-line weight request per step):
     //   256-row 97 / 120, bf16 101 / 124;  128-row 62 / 74, bf16 70 / 78 (profiles/r04/splitk_lab_run7*.jsonl);
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
-    int blk_cfg = -1;
+    int blk_cfg = -1, blk_sk = 0;                     // blk_sk: grid K split the cost model chose with the block shape (3 bits)
     double alt_us = -1.0;                             // modelled time of the best other MFMA kernel (set by the block cost model)
     const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32, 3-bit: 16)
     const bool b3_ok = bits != 3 || (size_t)3 * (N >> 4) * K * 2 < (size_t)0xfffffff0u;   // one descriptor over Q
@@ -594,7 +594,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (fixed
             // costs of ~8 us per call: prologue, fp32 slabs, reduce launch)
             blk_cfg = 12;
-        } else if (M >= 256) {
+        } else if (M >= 256 || (bits == 3 && M > 64)) {          // (3 bits from M = 65: the K-split candidates below)
             const bool bf = dtype == FLUTE_BF16;
             auto block_us = [&](long tiles, double alone, double busy) {
                 const long whole = tiles / num_sms, rest = tiles % num_sms;       // full rounds + a last partial one
@@ -617,6 +617,32 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
             else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
             alt_us = std::min(wave_us, std::min(t256, t128));
+            if (bits == 3) {
+                // 3-bit layers have no split-K block kernel of their own (qgemm_splitk.h: 2 / 4 bits): where whole blocks leave
+                // CUs idle, 128- or 64-row blocks of qgemm_block3.h with a grid K split (fp32 slabs + the reduce pass) fill
+                // them.  One round of workgroups; a block costs ~4 us + its K share of (128 rows: 78 / 85 us alone, 85 / 90 busy;
+                // 64 rows: 66 / 72 - the lookups of a block's 256 columns dominate, the rows are nearly free), the slabs 0.25 us
+                // per MB + the reduce launch.  Measured (bf16, profiles/r04/w3_mid_m_forced_plans.jsonl; before -> after):
+                // M = 1024 x 4096^2 84.9 -> 56.4 us, M = 512 x 8192^2 160.5 -> 95.6, M = 512 x 4096^2 54.5 -> 45.4
+                double best = blk_cfg == 4 ? t256 : (blk_cfg == 5 ? t128 : wave_us);
+                const int align_k = std::max(64, 8 << lg);
+                for (int rows = 128; rows >= 64; rows >>= 1) {
+                    const long tiles = (long)ceil_div(M, rows) * (units / blk_units);
+                    const double alone = rows == 128 ? (bf ? 85.0 : 78.0) : (bf ? 72.0 : 66.0);
+                    const double busy = rows == 128 ? (bf ? 90.0 : 85.0) : (bf ? 72.0 : 70.0);
+                    for (int sk = (rows == 128 ? 2 : 1); sk <= 4; sk *= 2) {
+                        const long wgs = tiles * sk;
+                        if (sk > 1 && (wgs > (long)num_sms || K % (sk * align_k) || K / sk < 1024 ||
+                                       (size_t)sk * M * N * 4 > slab_room(workspace_bytes))) continue;
+                        double us;
+                        if (sk == 1) us = block_us(tiles, alone, busy);
+                        else us = 4.0 + ((wgs * 4 >= (long)num_sms * 3 ? busy : alone) - 4.0) * (double)(K / sk) / 4096.0 + 5.0 +
+                                  0.25 * (double)sk * M * N * 4.0 / 1e6;
+                        if (us < 0.95 * best) { best = us; blk_cfg = rows == 128 ? 5 : 12; blk_sk = sk; }
+                    }
+                }
+                alt_us = std::min(alt_us, best);
+            }
         }
         if (blk_cfg >= 0) family = kFamilyBlock;
     }
@@ -682,8 +708,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         const int bm = block_rows(blk_cfg), tm = bm / 32;
         const int tiles_m = ceil_div(M, bm), tiles_n = units / (256 / J);
         const int align_k = std::max(64, 8 << lg);
-        int splitk = (ov.splitk > 0) ? ov.splitk : 1;
-        if (blk_cfg >= 8 && ov.splitk <= 0)                  // skinny blocks: the K split fills the chip
+        int splitk = (ov.splitk > 0) ? ov.splitk : (blk_sk > 0 ? blk_sk : 1);
+        if (blk_cfg >= 8 && ov.splitk <= 0 && blk_sk == 0)   // skinny blocks: the K split fills the chip
             while ((long)tiles_m * tiles_n * splitk * 2 <= (long)num_sms && K / (splitk * 2) >= std::max(256, align_k)) splitk *= 2;
         int kps = round_up(ceil_div(K, splitk), align_k);
         splitk = ceil_div(K, kps);

@@ -12,7 +12,9 @@
 // half step feeds both tiles, as for 4 bits - wave 6 takes (12,13) (two planes) and wave 7 takes (14,15): field 15
 // needs all three planes (5 VALU per lookup), one of which is field 14's.  Three instantiations of the body, chosen
 // by a wave-uniform branch; all execute the same barriers.
-// Everything else is qgemm_block2.h: RT = 8 (128-row blocks) or, round 3, RT = 16 (256-row blocks).  Wave 7's ring of
+// Everything else is qgemm_block2.h (round 4: activations as whole-line 8-row x 128-B pieces too: 3-bit M = 4096 on
+// 4096^2 130.0 -> 127.9 us, M = 1024 on 28672 x 8192 478 -> 466; the PLANE pieces are still 16 rows x 64 B - a whole-line
+// plane piece would need a cross-lane shuffle or a trip through LDS): RT = 8 (128-row blocks) or, round 3, RT = 16 (256-row blocks).  Wave 7's ring of
 // three plane pieces per half step x three stages is 72 registers - with 16 row tiles of accumulators (128) and every
 // wave of a kernel getting the same allocation, too many - so at RT = 16 the SECOND and THIRD plane pieces of waves 6
 // and 7 go to wave-private LDS by LDS-DMA (18 KB) and are read back, one half step ahead, with the fragments (246
@@ -89,11 +91,18 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const srd_t x_srd = make_srd(a.A, (uint32_t)min((size_t)a.M * a.K * 2, (size_t)0xfffffff0u));
     const srd_t w_srd = make_srd(a.Q, (uint32_t)min((size_t)(3 * (a.N >> 4)) * row_bytes, (size_t)0xfffffff0u));
     const srd_t s_srd = make_srd(a.S, (uint32_t)min((size_t)a.N * a.G * 2, (size_t)0xfffffff0u));
+    // Activations (round 4, as qgemm_block2.h: WHOLE cache lines - a request is priced per line it touches; before: 16 rows
+    // x 64 B): piece p = 2 rt + rh of a stage = rows 16 rt + 8 rh .. + 7, 128 B (the 64 k of the step) each; lane L fetches
+    // the 16-B chunk (L & 7) ^ blk_swz8(L >> 3, rh) of row L >> 3, written lane-linearly.  Rows past M read as zero (their
+    // byte offset is past the descriptor's range).
     const int p0 = wave * PH;
     const bool x_mine = p0 < PIECES;                               // (wave-uniform) skinny blocks have fewer pieces than waves
-    const uint32_t x_v0 = x_mine ? (uint32_t)(((size_t)(m0 + (p0 % RT) * 16 + (lane >> 2)) * a.K + (p0 / RT) * 32 +
-                                               ((lane & 3) ^ blk_swz(lane >> 2)) * 8) * 2) : 0x80000000u;
-    const uint32_t x_dv = 16u * row_bytes;
+    uint32_t x_vo[PH];
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+        const int rt = (p0 + i) >> 1, rh = (p0 + i) & 1, row8 = lane >> 3;
+        x_vo[i] = x_mine ? (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ blk_swz8(row8, rh)) * 8)) * 2) : 0x80000000u;
+    }
     // plane rows of this lane's unit (common.h unit_row<3>): plane 0 = row u, planes 1 / 2 = 32 rows apart
     const int u = unit0 + r16;
     const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
@@ -114,7 +123,10 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         }
     }
     const uint32_t lane_off = (uint32_t)(lane & 31) * 4u;
-    const uint32_t frag_lo = (uint32_t)LUT_BYTES + (uint32_t)(r16 * 4 + (q4 ^ blk_swz(r16))) * 16u;
+    // fragment of row tile R, half step h, stage slot: LUT + slot * STAGE_BYTES + R * 2048 + piece (r16 >> 3) * 1024 + row
+    // (r16 & 7) * 128 + position ((4 h + q4) ^ swz) * 16: half step 1 is 64 B away from half step 0, in the direction swz says
+    const uint32_t frag_l0 = (uint32_t)LUT_BYTES + (uint32_t)((r16 >> 3) * 1024 + (r16 & 7) * 128 + ((q4 ^ blk_swz8(r16 & 7, r16 >> 3)) * 16));
+    const uint32_t frag_l1 = frag_l0 ^ 64u;                        // (LUT_BYTES and the rest are multiples of 128)
     const uint32_t sc_lane = sc_base + (uint32_t)r16 * 16u;
 
     // ---- the body: three instantiations (see the header), the same barriers in each ----
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             constexpr int i = decltype(i_tag)::value;
             const uint32_t k0 = (uint32_t)(kbeg + min(ustep, nsteps - 1) * 64);
             if constexpr (i < PH) {
-                dma16_buf(x_v0 + (uint32_t)i * x_dv, x_srd, k0 * 2u,
+                dma16_buf(x_vo[i], x_srd, k0 * 2u,
                           x_lds0 + (x_mine ? (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES : 0u));
             } else if constexpr (i < PH + 2 * NPL) {
                 constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;
@@ -238,9 +250,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         };
         auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
-            constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + (decltype(h_tag)::value * RT + R) * 1024;
+            constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + R * 2048;
+            constexpr int hh = decltype(h_tag)::value;
             u32x4_t& dst = af[R & 7];
-            const uint32_t addr = off < 65536 ? frag_lo : frag_lo + 65536u;     // (named first: clang does not capture through asm operands)
+            const uint32_t fl = hh == 0 ? frag_l0 : frag_l1;
+            const uint32_t addr = off < 65536 ? fl : fl + 65536u;     // (named first: clang does not capture through asm operands)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off < 65536 ? off : off - 65536) : "memory");
         };
         auto wait_lds = [&]() {

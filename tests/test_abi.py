@@ -125,7 +125,10 @@ def test_plan_families_and_invariants():
     rc, p = plan(4096, 4096, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 3 and p.m_block == 4 and p.grid == 256 and p.lds_bytes == 146 * 1024    # 3 bits: 256-row blocks too (planes 2, 3 of two waves in LDS)
     rc, p = plan(1024, 4096, 4096, bits=3, tid=4)
-    assert rc == 0 and p.family == 3 and p.m_block == 5 and p.grid == 128 and p.lds_bytes == 80 * 1024     # fewer blocks: 128 rows
+    assert rc == 0 and p.family == 3 and p.m_block == 5 and (p.grid, p.splitk) == (256, 2) and p.lds_bytes == 80 * 1024     # fewer blocks: 128 rows x two K slices (round 4)
+    assert p.workspace_needed == 2 * 1024 * 4096 * 4 + 65536
+    rc, p = plan(1024, 4096, 4096, bits=3, tid=4, ws=1 << 20)
+    assert rc == 0 and p.splitk == 1                    # no room for the slabs: whole-K blocks
     rc, p = plan(300, 1024, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches

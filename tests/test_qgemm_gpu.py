@@ -496,7 +496,7 @@ def test_block_prefill_kernel(env):
     p = dev.get_plan(4096, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)
     assert p["family"] == 3 and p["m_block"] == 4 and p["grid"] == 256, p          # 3 bits: 256-row blocks (qgemm_block3.h, round 3)
     p = dev.get_plan(1024, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)
-    assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 128, p          # ... 128-row blocks where those fill more CUs
+    assert p["family"] == 3 and p["m_block"] == 5 and p["splitk"] == 2 and p["grid"] == 256, p   # ... 128-row blocks x two K slices (round 4) where whole blocks leave CUs idle
     assert dev.get_plan(700, 1024, 2048, 3, 64, 4, 256, torch.float16, dev.Overrides(family=3, m_tiles=8))["m_block"] == 4
 
 

@@ -58,6 +58,8 @@ def candidates(bits, M):
         c += [dict(family=5, splitk=sk) for sk in (1, 2, 4, 8)]
     if bits == 3 and 17 <= M <= 64:
         c += [dict(family=3, m_block=4), dict(family=3, m_block=2)]
+    if bits == 3 and M > 64:
+        c += [dict(family=3, m_tiles=4, splitk=sk) for sk in (2, 4)] + [dict(family=3, m_block=4, splitk=sk) for sk in (1, 2, 4)] + [dict(family=2)]
     if M >= 128:
         c += [dict(family=3, m_tiles=4), dict(family=3, m_tiles=8)]
         if bits != 3:
