@@ -355,7 +355,8 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
         const double steps = (double)K / sk / 128.0;           // 64-k steps of a K half
         const bool eform = sk == 2 || (sk == 4 && rt == 8);
         const double mb = sk == 1 ? 0.0 : (double)wgs * (slab_of(rt) * 1e-6) * (eform ? (sk - 1.0) / sk : 1.0);
-        const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : 1.5 + 0.5 * mb);
+        // (L form on 32-KB slabs, measured at M = 48 .. 96: 2.2 us at four slices / 3.4 at eight of 8.4 MB - profiles/r04/splitk_64_row_tiles_below_m128.json)
+        const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : (rt == 4 ? 1.5 + 0.15 * mb : 1.5 + 0.5 * mb));
         const double step = rt == 8 ? 0.65 + 0.31 * fill * fill * fill : 0.44 + 0.08 * fill * fill * fill;
         return rounds * (9.5 + steps * step) + seam;
     };
@@ -561,8 +562,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (src == FLUTE_OK && p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
         return src;
     }
-    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && M >= 128 && auto_digit_sk(bits, template_id);
-    if (sk_regime && t.stages == 5) {
+    // (round 4, late: 4-bit layers from M = 48 - 64-row tiles x K slices against the per-wave kernel: M = 64 x 8192^2 24.7 -> 20.0 us,
+    // M = 96 x 14336 x 4096 41.2 -> 24.6, M = 96 x 8192^2 45.3 -> 28.6)
+    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 48)) && auto_digit_sk(bits, template_id);
+    if (sk_regime && t.stages == 5 && M > 64) {       // (M <= 64: the table's Stages-5 ids of that bucket were tuned on the per-wave kernel's K split)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p, t.sms_multiple == 1 ? 0 : (t.sms_multiple == 2 ? 1 : 2)) == FLUTE_OK)
             return FLUTE_OK;
         memset(p, 0, sizeof(*p));
@@ -656,7 +659,13 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             const bool bf = dtype == FLUTE_BF16;
             int dbl = M < 256 ? -1 : 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;
-            const double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            if (M < 128) {
+                // per-wave kernel below M = 128 (measured fp16, tools/time_cases.py): 220 .. 280 TFLOP/s at M = 48, 270 .. 350 at
+                // M = 64 .. 96 on layers up to 14336 columns; 490 .. 570 on 28672 columns (two slabs per wave, every CU busy)
+                wave_tf = std::min(300.0, 5.5 * M) * (bf ? 0.8 : 1.0);
+                if (N >= 16384) wave_tf *= 1.8;
+            }
             alt_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
         }
         flute_plan q;
