@@ -129,6 +129,19 @@ def test_plan_families_and_invariants():
     assert p.workspace_needed == 2 * 1024 * 4096 * 4 + 65536
     rc, p = plan(1024, 4096, 4096, bits=3, tid=4, ws=1 << 20)
     assert rc == 0 and p.splitk == 1                    # no room for the slabs: whole-K blocks
+    rc, p = plan(128, 28672, 8192, bits=3, tid=4, dtype=1)
+    assert rc == 0 and (p.family, p.m_block, p.splitk, p.grid) == (3, 5, 2, 224)      # 3 bits from M = 65: blocks x K slices against the per-wave kernel
+    rc, p = plan(256, 4096, 4096, bits=3, tid=4, dtype=1)
+    assert rc == 0 and p.family == 2                    # ... which keeps the small layers (30.5 us against 32.5)
+    # 4-bit layers below M = 128 (round 4): 64-row tiles x K slices where the model beats the per-wave kernel, one round of workgroups
+    rc, p = plan(64, 8192, 8192)
+    assert rc == 0 and (p.family, p.m_tiles, p.splitk, p.grid, p.splitk_mode) == (6, 4, 4, 256, 1)
+    rc, p = plan(64, 28672, 8192)
+    assert rc == 0 and p.family == 2                    # two rounds of tiles: per-wave kernel (two slabs per wave)
+    rc, p = plan(47, 8192, 8192)
+    assert rc == 0 and p.family == 2
+    rc, p = plan(64, 8192, 8192, tid=17)
+    assert rc == 0 and p.family == 2                    # a tuned id (QuantMapMode digit 1) keeps the kernel it was timed on
     rc, p = plan(300, 1024, 4096, bits=3, tid=4)
     assert rc == 0 and p.family == 2                    # too few blocks: the per-wave MFMA kernel
     # decode kernel: planner shapes (any wave count), one-shot variant for single-visit launches
