@@ -562,9 +562,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (src == FLUTE_OK && p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
         return src;
     }
-    // (round 4, late: 4-bit layers from M = 48 - 64-row tiles x K slices against the per-wave kernel: M = 64 x 8192^2 24.7 -> 20.0 us,
-    // M = 96 x 14336 x 4096 41.2 -> 24.6, M = 96 x 8192^2 45.3 -> 28.6)
-    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 48)) && auto_digit_sk(bits, template_id);
+    // (round 4, late: 4-bit layers from M = 33, 2-bit layers from M = 65 - 64-row tiles x K slices against the per-wave kernel:
+    // M = 64 x 8192^2 24.7 -> 20.0 us, M = 33 23.7 -> 19.5, M = 96 x 14336 x 4096 41.2 -> 24.6, M = 96 x 8192^2 45.3 -> 28.6;
+    // 2 bits M = 96: 8192^2 43.3 -> 29.0, 14336 x 4096 40.5 -> 25.4; 2 bits at M = 64 gain 3 .. 9 % only: left alone)
+    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 33) || (bits == 2 && M >= 65)) && auto_digit_sk(bits, template_id);
     if (sk_regime && t.stages == 5 && M > 64) {       // (M <= 64: the table's Stages-5 ids of that bucket were tuned on the per-wave kernel's K split)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p, t.sms_multiple == 1 ? 0 : (t.sms_multiple == 2 ? 1 : 2)) == FLUTE_OK)
             return FLUTE_OK;

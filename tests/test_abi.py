@@ -138,7 +138,13 @@ def test_plan_families_and_invariants():
     assert rc == 0 and (p.family, p.m_tiles, p.splitk, p.grid, p.splitk_mode) == (6, 4, 4, 256, 1)
     rc, p = plan(64, 28672, 8192)
     assert rc == 0 and p.family == 2                    # two rounds of tiles: per-wave kernel (two slabs per wave)
-    rc, p = plan(47, 8192, 8192)
+    rc, p = plan(33, 8192, 8192)
+    assert rc == 0 and (p.family, p.m_tiles, p.splitk) == (6, 4, 4)
+    rc, p = plan(32, 8192, 8192)
+    assert rc == 0 and p.family == 2
+    rc, p = plan(96, 8192, 8192, bits=2, tid=0)
+    assert rc == 0 and (p.family, p.m_tiles, p.splitk, p.grid) == (6, 4, 2, 256)     # 2-bit layers from M = 65
+    rc, p = plan(64, 8192, 8192, bits=2, tid=0)
     assert rc == 0 and p.family == 2
     rc, p = plan(64, 8192, 8192, tid=17)
     assert rc == 0 and p.family == 2                    # a tuned id (QuantMapMode digit 1) keeps the kernel it was timed on
