@@ -67,14 +67,17 @@ typedef struct flute_template_info {
 typedef struct flute_plan {
     int family;          /* 0 = decode (GEMV kernels, M<=4; 3 bits: M<=2; see one_shot), 2 = MFMA kernel with
                             LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
-                            (4-bit, enough 128/256 x 256 output blocks to fill the chip), 5 = skinny MFMA kernel
+                            (enough 128 / 256 x 256 output blocks to fill the chip; 3-bit layers from M = 65 also 128- or
+                            64-row blocks x splitk K slices - m_block 5 / 12 - with fp32 slabs + the reduce pass), 5 = skinny MFMA kernel
                             (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
                             slabs fill 55..100 % of the CUs; weights and activations straight to registers),
                             6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, m_tiles x 16 rows (128 or 64) x 128 columns
                             output tiles x splitk K slices, one workgroup of 8 compute + 4 loader waves each, partial tiles
-                            combined inside the launch) */
-    int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit) */
-    int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4) */
+                            combined inside the launch; automatic from M = 33 (4 bits) / 65 (2 bits) where its modelled time
+                            is 8 % under the other MFMA kernels' and one round of workgroups covers the output) */
+    int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit); family 3: block shape
+                            (4 / 5: 256- / 128-row blocks; 8 + rt: 3-bit blocks of rt = 1, 2, 4 row tiles) */
+    int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4); family 6: row tiles per output tile (8 / 4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
     int waves;           /* waves per workgroup (decode: any count up to 16, not only powers of two) */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
