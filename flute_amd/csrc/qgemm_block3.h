@@ -25,6 +25,20 @@
 #pragma once
 #include "qgemm_block2.h"
 
+// Development variant, NOT measured yet (round 4 ended without GPU time for it; default 0 = off; 1 = every wave, 2 = all but the
+// wave of fields 14 / 15): the bit-plane pieces as WHOLE
+// cache lines too.  Today a plane piece is 16 unit rows x 64 B (one half step): 16 half lines per request, up to six requests
+// per step in the wave that owns field 15 - 350 line touches per step and CU against 64 for the 4-bit blocks, which is where
+// the static instruction mix says the 3-bit block's extra ~0.2 us per step goes (VALU per step: 52 .. 92 against 70 for 4
+// bits).  With the macro set a plane is fetched as two requests per STEP of 8 unit rows x 128 B (request A: units 0 .. 7,
+// request B: units 8 .. 15; lane (r16, q4) fetches chunk 4 (r16 >> 3) + q4 of unit r16 % 8): the same number of requests and
+// registers, half the lines; the words of half step h are put together by one DPP row_ror:8 move per dword (the scheme of
+// qgemm_block2.h's half_words, with two source registers), the LDS planes of the 256-row blocks are read back from the
+// source lane's slot.  tests/test_splitk_layout.py models the lane mapping.
+#ifndef FLUTE_B3_LINE_PLANES
+#define FLUTE_B3_LINE_PLANES 0
+#endif
+
 namespace flute_amd {
 
 template <typename T, int RT>
@@ -108,12 +122,21 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_p1 = (uint32_t)((a.N >> 4) + (u >> 5) * 64 + (u & 31)) * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_dp = 32u * row_bytes;
+    constexpr bool LINEP = FLUTE_B3_LINE_PLANES != 0;
+    // whole-line plane requests: unit (r16 & 7) [+ 8 for request B], chunk 4 (r16 >> 3) + q4 of its 128-B step
+    const int u8a = unit0 + (r16 & 7), u8b = u8a + 8;
+    const uint32_t lp_chunk = (uint32_t)((r16 >> 3) * 4 + q4) * 16u;
+    const uint32_t wvA_p0 = (uint32_t)u8a * row_bytes + lp_chunk, wvB_p0 = (uint32_t)u8b * row_bytes + lp_chunk;
+    const uint32_t wvA_p1 = (uint32_t)((a.N >> 4) + (u8a >> 5) * 64 + (u8a & 31)) * row_bytes + lp_chunk;
+    const uint32_t wvB_p1 = (uint32_t)((a.N >> 4) + (u8b >> 5) * 64 + (u8b & 31)) * row_bytes + lp_chunk;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
     // RT = 16 (256-row blocks): the SECOND and THIRD plane pieces of waves 6 / 7 go to wave-private LDS (LDS-DMA) instead of
     // the register ring - 16 row tiles of accumulators leave no registers for three planes x three stages x two half steps
     const uint32_t pl_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + NW * 3072u + (wave == 7 ? 6u * 1024u : 0u);   // wave-uniform (M0 of the DMA)
+    // (whole-line planes: the 16 B of half step h were fetched by lane (r16 % 8 + 8 h, q4) of request r16 >> 3; + 128 h is immediate)
     const uint32_t pl_lane = pl_base + (uint32_t)lane * 16u;
+    const uint32_t pl_lane_lp = pl_base + (uint32_t)(q4 * 16 + (r16 & 7)) * 16u;
     const uint32_t x_lds0 = x_mine ? (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u : sc_sink;     // idle request: zeros into the sink
 
     {   // pair table: 64 entries, 32 copies each (128-B stride)
@@ -134,6 +157,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         // KIND 0: both fields in one plane (one piece per half step); 1: two planes; 2: fields 14 and 15 (three planes)
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool LAST = KIND == 2;
+        constexpr bool LP = LINEP && !(LAST && FLUTE_B3_LINE_PLANES == 2);   // (2: the wave of fields 14 / 15 keeps its half-step pieces: + 44 VALU per step there otherwise)
         constexpr int NPL = KIND + 1;                              // weight pieces per half step
         constexpr int BATCH = PH + 2 * NPL + 1;
         constexpr int RPR = (BATCH + RT - 1) / RT;                 // requests issued after every row tile of half step 0
@@ -144,6 +168,9 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         const int pl0 = f0 % 3, pl1 = f1 % 3;
         const uint32_t wv0 = (pl0 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl0 - 1) * wv_dp;
         const uint32_t wv1 = (pl1 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl1 - 1) * wv_dp;
+        // (whole-line planes) the same for the two requests of a step: [request][tile's plane]
+        const uint32_t wvl[2][2] = {{(pl0 == 0) ? wvA_p0 : wvA_p1 + (uint32_t)(pl0 - 1) * wv_dp, (pl1 == 0) ? wvA_p0 : wvA_p1 + (uint32_t)(pl1 - 1) * wv_dp},
+                                    {(pl0 == 0) ? wvB_p0 : wvB_p1 + (uint32_t)(pl0 - 1) * wv_dp, (pl1 == 0) ? wvB_p0 : wvB_p1 + (uint32_t)(pl1 - 1) * wv_dp}};
         // scale block: lane L < 32 fetches 8 groups of column (unit L % 16, field f_(L / 16)); lane-linear image
         const uint32_t s_voff = (lane < 32)
             ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 15)) + ((lane >> 4) ? f1 : f0) * TILEP) * a.G) * 2) : 0x80000000u;
@@ -154,6 +181,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         constexpr int NX = NPL - NREG;
         u32x4_t w[NST][2][NREG];
         u32x4_t pw[NX > 0 ? NX : 1];                               // the LDS planes of the NEXT half step
+        const uint32_t pl_lane_k = LP ? pl_lane_lp + (uint32_t)(r16 >> 3) * (uint32_t)((NX > 0 ? NX : 1) * 1024) : pl_lane;
         auto issue_one = [&](auto slot_tag, auto i_tag, int ustep) {
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int i = decltype(i_tag)::value;
@@ -162,14 +190,18 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 dma16_buf(x_vo[i], x_srd, k0 * 2u,
                           x_lds0 + (x_mine ? (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES : 0u));
             } else if constexpr (i < PH + 2 * NPL) {
-                constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;
+                constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;        // (whole-line planes: h = request A / B of the step)
                 uint32_t vo;
-                if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
+                if constexpr (LP) {
+                    if constexpr (LAST) vo = (c == 0) ? (h ? wvB_p0 : wvA_p0) : (h ? wvB_p1 : wvA_p1) + (uint32_t)(c - 1) * wv_dp;
+                    else vo = wvl[h][c == 0 ? 0 : 1];
+                } else if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
                 else vo = (c == 0) ? wv0 : wv1;
+                const uint32_t so = k0 * 2u + (LP ? 0u : (uint32_t)h * 64u);
                 if constexpr (XLDS && c >= 1)
-                    dma16_buf(vo, w_srd, k0 * 2u + (uint32_t)h * 64u, pl_base + (uint32_t)(((slot * 2 + h) * NX + (c - 1)) * 1024));
+                    dma16_buf(vo, w_srd, so, pl_base + (uint32_t)(((slot * 2 + h) * NX + (c - 1)) * 1024));
                 else
-                    w[slot][h][c] = buf_load16(vo, w_srd, k0 * 2u + (uint32_t)h * 64u);
+                    w[slot][h][c] = buf_load16(vo, w_srd, so);
             } else {
                 const int g = (int)(k0 >> a.lg);
                 const bool blk_start = (ustep < nsteps) && ((g & 7) == 0 || ustep == 0) && ((k0 & ((1u << a.lg) - 1u)) == 0);
@@ -222,17 +254,29 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         auto lookup = [&](auto slot_tag, auto h_tag, auto n_tag) {
             constexpr int n = decltype(n_tag)::value;              // tile n / 4, word n % 4
             constexpr int ww = n & 3;
-            const u32x4_t& q0 = w[decltype(slot_tag)::value][decltype(h_tag)::value][0];
-            const u32x4_t& q1 = XLDS ? pw[0] : w[decltype(slot_tag)::value][decltype(h_tag)::value][NREG > 1 ? 1 : 0];
-            const u32x4_t& q2 = XLDS ? pw[NX > 1 ? 1 : 0] : w[decltype(slot_tag)::value][decltype(h_tag)::value][NREG > 2 ? 2 : 0];
+            constexpr int S_ = decltype(slot_tag)::value, H_ = decltype(h_tag)::value;
+            // word ww of register plane c for this lane's (unit, half step): the ring register itself, or (whole-line planes) put
+            // together from the two requests of the step - lanes r16 < 8 hold their unit in request A, lanes >= 8 in request B, the
+            // half step a lane lacks sits 8 lanes away in the same row (DPP row_ror:8, as qgemm_block2.h's half_words)
+            auto ring_word = [&](auto c_tag) -> uint32_t {
+                constexpr int c = decltype(c_tag)::value;
+                if constexpr (!LP) return w[S_][H_][c][ww];
+                else if constexpr (H_ == 0)
+                    return (uint32_t)__builtin_amdgcn_update_dpp((int)w[S_][0][c][ww], (int)w[S_][1][c][ww], 0x128 /* row_ror:8 */, 0xf, 0xc, false);
+                else
+                    return (uint32_t)__builtin_amdgcn_update_dpp((int)w[S_][1][c][ww], (int)w[S_][0][c][ww], 0x128 /* row_ror:8 */, 0xf, 0x3, false);
+            };
+            const uint32_t q0w = ring_word(std::integral_constant<int, 0>{});
+            const uint32_t q1w = XLDS ? pw[0][ww] : ring_word(std::integral_constant<int, (NREG > 1 ? 1 : 0)>{});
+            const uint32_t q2w = XLDS ? pw[NX > 1 ? 1 : 0][ww] : ring_word(std::integral_constant<int, (NREG > 2 ? 2 : 0)>{});
             uint32_t idx;
             if constexpr (LAST) {
-                if constexpr (n < 4) idx = __builtin_amdgcn_ubfe(q2[ww], 24u, 6u);                 // field 14: plane 2, bit 24
-                else idx = (q0[ww] >> 30) | ((q1[ww] >> 28) & 0xcu) | ((q2[ww] >> 26) & 0x30u);      // field 15 (common.h field<3>)
+                if constexpr (n < 4) idx = __builtin_amdgcn_ubfe(q2w, 24u, 6u);                    // field 14: plane 2, bit 24
+                else idx = (q0w >> 30) | ((q1w >> 28) & 0xcu) | ((q2w >> 26) & 0x30u);              // field 15 (common.h field<3>)
             } else if constexpr (n < 4) {
-                idx = __builtin_amdgcn_ubfe(q0[ww], sh0, 6u);
+                idx = __builtin_amdgcn_ubfe(q0w, sh0, 6u);
             } else {
-                idx = __builtin_amdgcn_ubfe((KIND == 0 ? q0 : q1)[ww], sh1, 6u);
+                idx = __builtin_amdgcn_ubfe(KIND == 0 ? q0w : q1w, sh1, 6u);
             }
             v[n] = lds_lookup32((idx << 7) | lane_off);
         };
@@ -241,9 +285,10 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 [&]<int... C>(std::integer_sequence<int, C...>) {
                     (([&] {
                         u32x4_t& dst = pw[C];
-                        const uint32_t addr = pl_lane;
+                        const uint32_t addr = pl_lane_k;
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr),
-                                     "n"(((decltype(slot_tag)::value * 2 + decltype(h_tag)::value) * NX + C) * 1024) : "memory");
+                                     "n"(LP ? (decltype(slot_tag)::value * 2 * NX + C) * 1024 + decltype(h_tag)::value * 128
+                                               : ((decltype(slot_tag)::value * 2 + decltype(h_tag)::value) * NX + C) * 1024) : "memory");
                     }()), ...);
                 }(std::make_integer_sequence<int, NX>{});
             }

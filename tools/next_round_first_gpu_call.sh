@@ -9,6 +9,14 @@
 #   2. the planner regret sweep at the batch sizes BETWEEN the ones round 4 swept (its candidate list now offers 3-bit blocks x
 #      K slices): every case over 10 % is a threshold to fix.
 # Copy gpurun_out/tuned_challenged.json over flute_amd/data/gfx950_tuned.json afterwards (tests/test_host.py checks the table).
+#   3. (second call) the 3-bit block kernel's whole-line PLANE pieces (qgemm_block3.h, FLUTE_B3_LINE_PLANES = 1 / 2; lane mapping
+#      modelled in tests/test_splitk_layout.py, never run): build HERE, before the call,
+#          make -C flute_amd/csrc -j OBJDIR=build_lp1 LIB=libflute_amd_lp1.so TORCHLIB=libflute_amd_torch_lp1.so EXTRA=-DFLUTE_B3_LINE_PLANES=1
+#      and on the box (its copy of the tree is scratch) put it in the library's place, then parity + timing:
+#          cp flute_amd/csrc/libflute_amd_lp1.so flute_amd/csrc/libflute_amd.so
+#          timeout 120 python -m pytest tests/test_qgemm_gpu.py -x -q -m gpu -k block_prefill
+#          python tools/time_cases.py "3,4096,4096,4096,bf16;3,1024,28672,8192,bf16;3,1024,4096,4096,bf16;3,256,8192,8192,bf16"
+#      (round 4, default build: 127.9 / 466 / 56.3 / 55.9 us).  Keep whichever of 0 / 1 / 2 wins; delete the others.
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
