@@ -506,7 +506,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // round 4: 2- / 4-bit layers up to 16 M weights take the four-row one-shot kernel at M = 3, 4 too (4096^2 M = 4: 6.3 us
     // against 7.1 on the MFMA kernel, profiles/r04_planner_regret_before_fixes.json - the one-shot kernel of round 3 was not
     // there when the MFMA kernel was measured level with the ring kernel)
-    const bool small_b24 = bits != 3 && ov.family < 0 && M >= 3 && (size_t)N * K <= ((size_t)16 << 20);
+    // (only ids whose last digit leaves the choice to the planner: a 4-bit id with QuantMapMode digit 3 keeps the skinny MFMA kernel it was
+    // tuned on - "a tuned id keeps the kernel it was timed on", tests/test_abi.py)
+    const bool small_b24 = bits != 3 && ov.family < 0 && M >= 3 && (size_t)N * K <= ((size_t)16 << 20) && auto_digit_sk(bits, template_id);
     const bool auto_digit = (bits == 4) ? (template_id % 4) == 0 : t.sms_multiple == 1;
     // decode planners: a fused Hadamard rotation prefers 8-wave workgroups (4096x3584 M = 1: 5.5 us with 8 waves, 6.5 with
     // the 4-wave shape the plain product takes)
@@ -565,7 +567,10 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // (round 4, late: 4-bit layers from M = 33, 2-bit layers from M = 65 - 64-row tiles x K slices against the per-wave kernel:
     // M = 64 x 8192^2 24.7 -> 20.0 us, M = 33 23.7 -> 19.5, M = 96 x 14336 x 4096 41.2 -> 24.6, M = 96 x 8192^2 45.3 -> 28.6;
     // 2 bits M = 96: 8192^2 43.3 -> 29.0, 14336 x 4096 40.5 -> 25.4; 2 bits at M = 64 gain 3 .. 9 % only: left alone)
-    const bool sk_regime = ov.family < 0 && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 33) || (bits == 2 && M >= 65)) && auto_digit_sk(bits, template_id);
+    // (overrides of the per-wave kernel - m_tiles, waves, kw, splitk, slabs - mean something else in plan_splitk: a call that sets
+    // any of them without family = 6 keeps the per-wave / block kernels)
+    const bool wave_ovr = ov.m_tiles > 0 || ov.waves > 0 || ov.kw > 0 || ov.splitk > 0 || ov.slabs > 0 || ov.m_block > 0;
+    const bool sk_regime = ov.family < 0 && !wave_ovr && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 33) || (bits == 2 && M >= 65)) && auto_digit_sk(bits, template_id);
     if (sk_regime && t.stages == 5 && M > 64) {       // (M <= 64: the table's Stages-5 ids of that bucket were tuned on the per-wave kernel's K split)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p, t.sms_multiple == 1 ? 0 : (t.sms_multiple == 2 ? 1 : 2)) == FLUTE_OK)
             return FLUTE_OK;
@@ -1097,7 +1102,9 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         float hs = had_scale;
         uint64_t* stamps = nullptr;
 #ifdef FLUTE_STAMPS
-        if (workspace && workspace_bytes >= (size_t)p.grid * p.waves * 128) stamps = reinterpret_cast<uint64_t*>(workspace);
+        // behind the xwg state words (bytes [0, 64 KB) must stay zero between calls)
+        if (workspace && workspace_bytes >= kXwgFlagBytes + (size_t)p.grid * p.waves * 128)
+            stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
 #endif
         void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &M, &D, &hs, &stamps};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=

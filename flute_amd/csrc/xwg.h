@@ -101,11 +101,16 @@ __device__ __forceinline__ uint32_t xwg_sweep(xwg_word* st, uint32_t nsl, uint32
     if (tid == 0) {
         const uint32_t want = ((1u << nsl) - 1u) & ~(1u << mine);
         uint32_t w1 = 0;
-        for (unsigned spin = 0; spin < ((kXwgSpinLimit > 4096u ? kXwgSpinLimit : 4096u) << 4); ++spin) {   // (a bound for form's sake: every owner's poll is bounded)
+        // every owner's poll is bounded, so this loop ends by itself; the bound only guards against a hung chip.  Expiry is FATAL
+        // (the launch traps and the stream reports an error): carrying on with an incomplete abandoned set would skip shares nobody
+        // combined and reset state words an owner may still OR into - silent, persistent corruption of the shared workspace.
+        bool done = false;
+        for (unsigned spin = 0; spin < ((kXwgSpinLimit > 4096u ? kXwgSpinLimit : 4096u) << 8); ++spin) {
             w1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((((w1 | (w1 >> 16)) & want) == want)) break;
+            if ((((w1 | (w1 >> 16)) & want) == want)) { done = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
+        if (!done) __builtin_trap();
         *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)bcast = (w1 >> 16) & want;
     }
     __syncthreads();

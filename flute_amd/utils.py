@@ -36,9 +36,14 @@ def get_device_num_sms(device: torch.device) -> int:
 
 def make_workspace_streamk(device: torch.device) -> torch.Tensor:
     """Zero-filled scratch for the grid-level K split (flute/utils.py:36-45).
-    The gfx950 kernels only use it for fp32 split-K slabs (splitk*M*N*4 bytes,
-    chosen so that it fits), so 64 MiB replaces the reference's
-    blocks*threads*2048-byte formula (537 MB for 256 CUs)."""
+    Layout (csrc/api.hip, csrc/xwg.h): bytes [0, 64 KB) hold two state words per
+    output tile for the in-launch reductions - zero when a call starts and zero
+    again when it ends, as the reference's barrier region
+    (tile_scheduler_utils.hpp:196) -, the fp32 split-K slabs follow
+    (splitk*M*N*4 bytes for the two-launch form, [splitk][tile] x 64 KB in
+    MFMA-fragment order for the in-launch form; the planner only takes splits
+    that fit).  64 MiB replaces the reference's blocks*threads*2048-byte
+    formula (537 MB for 256 CUs)."""
     return torch.zeros(64 * 1024 * 1024, dtype=torch.uint8, device=device)
 
 

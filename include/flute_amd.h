@@ -106,8 +106,10 @@ typedef struct flute_plan {
  *                   6 split-K block kernel (splitk picks the K slices per tile; 1 = none; m_tiles 8 / 4: 128- / 64-row
  *                   tiles; waves 8 = without the four loader waves);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
- *                   small layers called with a Hadamard size, to keep the rotation fused), 2 (or any other value
- *                   >= 1) per-wave MFMA kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block)
+ *                   small layers called with a Hadamard size, to keep the rotation fused), 1 / 2 per-wave MFMA
+ *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 6 are rejected
+ *                   (FLUTE_ERR_SHAPE).  m_tiles / waves / kw / splitk / slabs_per_wave given WITHOUT family = 6 belong to the
+ *                   per-wave kernel: such a call never takes the split-K block kernel automatically
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)
  *   waves, kw       waves per workgroup / in-workgroup K split
  *   splitk          grid-level K split

@@ -252,7 +252,7 @@ def test_plan_invariants_over_random_shapes():
         K = rng.choice([256, 512, 1024, 2048, 3584, 4096, 4096 + 64, 5120, 8192, 11008, 14336, 28672])
         if K % g:
             continue
-        M = rng.choice([1, 1, 2, 3, 4, 5, 8, 16, 17, 32, 64, 128, 256, 1000, 4096])
+        M = rng.choice([1, 1, 2, 3, 4, 5, 8, 16, 17, 32, 33, 48, 64, 65, 96, 127, 128, 256, 1000, 4096])
         num_sms = rng.choice([256, 256, 256, 304, 8, 120])
         dtype = rng.choice([0, 1])
         rc = lib.flute_qgemm_plan_ex(dtype, bits, g, M, N, K, tid, num_sms, 64 << 20, None, p)
@@ -290,7 +290,7 @@ def test_plan_invariants_over_random_shapes():
         elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
             assert p.m_tiles in (8, 4), what                      # 128- / 64-row tiles
             tiles = -(-M // (p.m_tiles * 16)) * (N // 128)
-            assert bits in (2, 4) and M >= 128 and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
+            assert bits in (2, 4) and M >= (33 if bits == 4 else 65) and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
             assert p.k_per_split * p.splitk == K and p.k_per_split % (2 * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
             gh = p.k_per_split // 2 // g
             assert gh + (7 if gh % 8 else 0) <= 32, what
@@ -303,6 +303,27 @@ def test_plan_invariants_over_random_shapes():
     # the sweep reaches every kernel of the library
     for key in ((0, 0), (0, 1), (0, 2), (0, 3), (2, 0), (3, 0), (5, 0), (6, 0)):
         assert fams.get(key, 0) > 0, (key, fams)
+
+
+def test_tuned_digit3_ids_keep_the_skinny_kernel_at_m3_m4():
+    """a 4-bit id with QuantMapMode digit 3 was tuned on the skinny MFMA kernel; the round-4 rule that sends
+    small 2- / 4-bit layers to the four-row decode kernel at M = 3, 4 applies to automatic-digit ids only."""
+    for (N, K) in ((4608, 2048), (8192, 2048), (4096, 4096)):
+        for M in (3, 4, 8):
+            rc, p = plan(M, N, K, tid=19)
+            assert rc == 0 and p.family == 5, (M, N, K, p.family, p.one_shot)
+        rc, p = plan(4, N, K, tid=16)                      # automatic digit: the planner's own choice (decode kernel on <= 16 M weights)
+        assert rc == 0 and p.family == 0, (N, K, p.family)
+
+
+def test_per_wave_overrides_are_not_reinterpreted_by_the_splitk_planner():
+    """m_tiles / waves / splitk given WITHOUT family = 6 belong to the per-wave kernel."""
+    lib = _lib.get()
+    q = _lib.Plan()
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 256, 11008, 4096, 16, 256, 64 << 20, _lib.Overrides(m_tiles=2), q) == 0
+    assert q.family == 2 and q.m_tiles == 2, (q.family, q.m_tiles)
+    assert lib.flute_qgemm_plan_ex(0, 4, 64, 256, 11008, 4096, 16, 256, 64 << 20, _lib.Overrides(family=6, m_tiles=4), q) == 0
+    assert q.family == 6 and q.m_tiles == 4
 
 
 def test_plan_rejects_bad_arguments():
