@@ -132,19 +132,40 @@ def flush_l3(device):
     _FLUSH[(device, "sink")].add_(buf.sum())
 
 
+LAST_TIMING = {}        # of the latest time_graph call: the HIP-event time of the same replay, the clock used
+
+
+def _timestamp(ts, slot):
+    """Enqueue (capture) a one-lane kernel that writes the chip-wide 100 MHz clock to ts[slot] (flute_debug_timestamp)."""
+    from flute_amd import _lib
+    import ctypes
+    rc = _lib.get().flute_debug_timestamp(ctypes.c_void_p(ts.data_ptr() + 8 * slot),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        raise RuntimeError(f"flute_debug_timestamp: {rc}")
+
+
 def time_graph(layer, steps, warmup, sync, cold=True):
-    """Capture `steps` launches in one hipGraph, replay once, timed by HIP events on
-    the replay stream and by the host clock around sync().  cold: flush the caches (untimed) before the timed
-    replay."""
+    """Capture `steps` launches in one hipGraph, bracketed INSIDE the graph by two device-clock stamps (one-lane kernels
+    writing the chip-wide 100 MHz clock: the first runs when everything before it has finished, the second when the last
+    step has), replay once.  Returns (ms between the stamps, host wall ms around sync()).  HIP events around the same replay
+    are recorded too (LAST_TIMING["events_ms"]): a graph launch bracketed by events carries a FIXED 16 - 19 us of launch /
+    marker overhead per replay whatever it holds (profiles/r05/graph_replay_fixed_cost_probe.json: 97.6 us for 20 steps,
+    183.0 for 40, 8190 for 2000 - slope 4.09 us per step at every length), i.e. +0.8 us per step at 20 steps and nothing
+    at 2000; the stamps see the launches themselves.  cold: flush the caches (untimed) before the timed replay."""
     for i in range(warmup):
         layer.step(i)
+    dev = torch.device("cuda", torch.cuda.current_device())
     if cold:
-        flush_l3(torch.device("cuda", torch.cuda.current_device()))     # first call: allocation + kernel load, out of the way
+        flush_l3(dev)     # first call: allocation + kernel load, out of the way
+    ts = torch.zeros(2, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
+        _timestamp(ts, 0)
         for i in range(steps):
             layer.step(warmup + i)
+        _timestamp(ts, 1)
     # untimed: the first replay pays the upload; then ~30 ms of replays so that the chip is at its sustained clocks
     # when the timed replay starts (a 20-step replay lasts 90 us - far shorter than a clock ramp; measured: 5.9 us
     # per step straight after the tuner's idle gap, 4.9 us after a sustained warm-up)
@@ -160,7 +181,7 @@ def time_graph(layer, steps, warmup, sync, cold=True):
     sync()
     t0 = time.perf_counter()
     if cold:
-        flush_l3(torch.device("cuda", torch.cuda.current_device()))     # stream-ordered, in front of the start event
+        flush_l3(dev)     # stream-ordered, in front of the start event
     else:
         graph.replay()                  # untimed spacer: the GPU stays busy while the host enqueues the timed replay
     start.record()
@@ -169,7 +190,16 @@ def time_graph(layer, steps, warmup, sync, cold=True):
     torch.cuda.synchronize()
     sync()
     wall_ms = (time.perf_counter() - t0) * 1e3
-    return start.elapsed_time(end), wall_ms
+    ev_ms = start.elapsed_time(end)
+    t = ts.cpu()
+    dev_ms = float(int(t[1]) - int(t[0])) * 1e-5            # ticks of 10 ns
+    LAST_TIMING.clear()
+    LAST_TIMING.update({"events_ms": ev_ms, "device_clock_ms": dev_ms})
+    if not (0.0 < dev_ms <= ev_ms * 1.001 + 0.01):           # a stamp that did not run: fall back on the events, and say so
+        LAST_TIMING["clock"] = "hip events (device stamps implausible)"
+        return ev_ms, wall_ms
+    LAST_TIMING["clock"] = "device clock stamps inside the graph"
+    return dev_ms, wall_ms
 
 
 def time_eager(layer, steps, warmup):
@@ -356,11 +386,12 @@ def main():
     else:
         tid = layer.tune()
     ev_ms, wall_ms = time_graph(layer, args.steps, args.warmup, sync)
+    headline_timing = dict(LAST_TIMING)
     eager_ms = time_eager(layer, min(args.steps, 500), 10)
-    t = torch.tensor([ev_ms, wall_ms], device=device, dtype=torch.float64)
+    t = torch.tensor([ev_ms, wall_ms, headline_timing["events_ms"]], device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ev_ms, wall_ms = t.tolist()
+    ev_ms, wall_ms, hip_events_ms = t.tolist()
     ms_per_step = ev_ms / args.steps
     bytes_step = layer.bytes()
     value = world * bytes_step / (ms_per_step * 1e-3) / 1e9
@@ -496,13 +527,14 @@ def main():
         plan = flute_amd.utils.get_plan(M, N, K, bits, g, tid, layer.num_sms, dtype)
         # HBM bytes per launch from the committed PMC passes of THIS command (tools/prof_bench.sh writes the file
         # together with the plan it profiled): reported only while the plan is still the one that was profiled
-        traffic, traffic_src = None, None
+        traffic, traffic_src, rocprof_us, rocprof_med_us = None, None, None, None
         import glob
         tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_traffic.json")))     # newest round last
         if tpaths:
             tj = json.load(open(tpaths[-1]))
             if tj.get("plan") == plan:
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(tpaths[-1])
+                rocprof_us, rocprof_med_us = tj.get("kernel_us_rocprof_avg"), tj.get("kernel_us_rocprof_median")
         # the floor of THIS launch shape: a pure read of the same packed bytes, requested the way the kernel requests them, in
         # the same kind of replayed graph (stand-alone harness, newest profiles/r*_calibration_stream_read.json)
         floor_us, floor_src = None, None
@@ -523,13 +555,39 @@ def main():
             "pure_read_floor_us": floor_us, "pure_read_floor_source": floor_src,
             "frac_of_pure_read_floor": None if floor_us is None else round(floor_us / (ms_per_step * 1e3), 4),
             "bytes_per_launch": bytes_step,
-            "kernel_us_events": round(ms_per_step * 1e3, 3),
-            "note": "events bracket the graph replay on its stream: includes inter-kernel gaps; traffic = "
-                    "2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction, MI355X_MICROARCH.md); a pure read of "
-                    "the same bytes, requested the same way, takes 2.8 us per launch and an empty kernel 1.9 us in the stand-alone "
-                    "harness (profiles/r03_calibration_stream_read.json); rocprofv3 kernel-trace serialises replayed graph "
-                    "launches at >= 4 us each, an empty kernel included (profiles/r03_rocprof/lab_traced_vs_untraced.txt)",
+            "kernel_us": round(ms_per_step * 1e3, 3),
+            "kernel_us_clock": headline_timing.get("clock"),
+            "kernel_us_hip_events": round(hip_events_ms / args.steps * 1e3, 3),
+            "kernel_us_rocprof": rocprof_us, "kernel_us_rocprof_median": rocprof_med_us,
+            "kernel_us_rocprof_source": traffic_src,
+            "achieved_from_rocprof_avg": None if not rocprof_us else round(bytes_step / rocprof_us / 1e3, 1),
+            "note": "kernel_us = (second device-clock stamp - first) / steps: two one-lane stamp kernels captured in the graph "
+                    "around the steps (period of back-to-back dependent launches, inter-kernel gaps included); "
+                    "kernel_us_hip_events = HIP events around the same replay / steps: carries the fixed 16 - 19 us a graph launch "
+                    "costs between its bracketing events whatever it holds, i.e. + 0.8 us per step at 20 steps, ~0 at 2000 "
+                    "(profiles/r05/graph_replay_fixed_cost_probe.json); kernel_us_rocprof = average duration of the kernel in the "
+                    "committed rocprofv3 --kernel-trace of this command (the tracer serialises replayed graph launches: an upper "
+                    "bound, profiles/r03_rocprof/lab_traced_vs_untraced.txt); traffic = 2*FETCH_SIZE + WRITE_SIZE per launch "
+                    "(gfx950 correction, MI355X_MICROARCH.md); a pure read of the same bytes, requested the same way, takes 2.8 us "
+                    "per launch and an empty kernel 1.9 us in the stand-alone harness (profiles/r03_calibration_stream_read.json)",
         }
+        # the second half of BASELINE.json's metric (TFLOP/s at M = 256) next to the roofline block: the extras entry of the same
+        # shape, with the HBM traffic / MFMA-busy figures of the committed PMC passes while the plan is the one they were taken on
+        m256 = None
+        for e in extras:
+            if e.get("workload") == "W4G64 fp16 M=256 K=4096 N=4096":
+                m256 = {"workload": e["workload"], "us": e["us"], "TFLOPs": e["TFLOPs"], "bound": "mfma", "peak": MFMA_PEAK_TFLOPS,
+                        "frac_mfma": e["frac_mfma_2.5PF"], "speedup_vs_torch_mm": e.get("speedup_vs_torch_mm"),
+                        "template_id": e["template_id"], "algorithmic_bytes": algorithmic_bytes(256, 4096, 4096, bits, g),
+                        "traffic": None, "mfma_busy_frac_chip": None, "pmc_source": None}
+                mp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_m256_pmc.json")))
+                if mp:
+                    mj = json.load(open(mp[-1]))
+                    mplan = flute_amd.utils.get_plan(256, 4096, 4096, bits, g, e["template_id"], layer.num_sms, dtype)
+                    if mj.get("plan") == mplan:
+                        m256.update({"traffic": mj.get("hbm_bytes_per_launch"), "mfma_busy_frac_chip": mj.get("mfma_busy_frac_chip"),
+                                     "kernel_us_rocprof_median": mj.get("kernel_us_rocprof_median"),
+                                     "pmc_source": "profiles/" + os.path.basename(mp[-1])})
         out = {
             "metric": replicas["metric"],
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
@@ -542,9 +600,10 @@ def main():
                                  "timed step streams its weights from HBM for any --steps",
             "config": {"workload": "W4G64 NF4 fp16 qgemm, M=1, K=4096, N=4096 (BASELINE configs[1])",
                        "template_id": tid, "plan": plan,
-                       "launch": "hipGraph replay of all steps",
+                       "launch": "hipGraph replay of all steps, timed by two device-clock stamps captured around them",
                        "parallelism": replicas["parallelism"]},
             "roofline": roofline,
+            "m256": m256,
             "cache_resident": {"us": round(hot_ms / args.steps * 1e3, 3),
                                "GBps": round(bytes_step / (hot_ms / args.steps * 1e-3) / 1e9, 1)},
             "eager_us_per_step": round(eager_ms / min(args.steps, 500) * 1e3, 3),

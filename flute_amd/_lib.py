@@ -58,6 +58,7 @@ SYMBOLS = {
     "flute_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
     "flute_unpack": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "flute_debug_stream_read": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "flute_debug_timestamp": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "qgemm_stream.h"
 #include "qgemm_persist.h"
+#include "qgemm_fast.h"
 #include "qgemm_skinny.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
@@ -216,6 +217,44 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
     p->lds_bytes = s.lds; p->lut_copies = 32;
     p->ring_depth = s.depth; p->visits = 1; p->k_chunks = 1; p->one_shot = 1 + s.pipe;
     if (oa) { oa->lg = lg; oa->lkw = ilog2(s.kw); oa->upw = s.upw; oa->pk = s.pk; oa->ipw = s.ipw; oa->depth = s.depth; oa->pipe = s.pipe; }
+    return FLUTE_OK;
+}
+
+// Lean one-row kernel (qgemm_fast.h, round 5): 4 bits, M = 1, K = 512 * D * KW a power of two.  Shapes (waves per workgroup, waves
+// per unit row, pieces per wave) by K, first choice first - measured in tools/ubench/oneshot_lab (profiles/r05/fast_lab_run*.jsonl;
+// us per launch next to the round-4 one-shot kernel in the same harness): K = 4096: (4, 1, 8) 4.24 / (8, 2, 4) 4.35 against 4.43
+// on 4096 x 4096, 7.49 / 7.50 against 8.63 on 4096 x 11008; K = 8192: (8, 2, 8) 6.50 on 8192 x 4096 (g = 128).  rank = the
+// template's Stages - 2.
+int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int want_waves, flute_plan* p, OneArgs* oa) {
+    if (bits != 4 || M != 1 || lg < 6 || lg > 8) return FLUTE_ERR_SHAPE;
+    struct Shape { int W, KW, D; };
+    std::vector<Shape> c;
+    if (K == 2048) c = {{4, 1, 4}};
+    else if (K == 4096) {
+        // one round of workgroups (<= one per CU): a wave per unit row, no cross-wave sum (4096^2: 4.05 us against 4.16 with
+        // 8 waves); more rounds: two waves per SIMD hide each other's stalls (11008: 6.86 against 6.97, 5120: 4.90 / 5.15,
+        // 8192: 5.46 / 5.54 - profiles/r05/time_cases_lean_shapes.jsonl)
+        if (N / 16 <= num_sms) c = {{4, 1, 8}, {8, 2, 4}};
+        else c = {{8, 2, 4}, {4, 1, 8}};
+    } else if (K == 8192) c = {{8, 2, 8}};
+    else return FLUTE_ERR_SHAPE;
+    Shape sh = c[std::min((size_t)std::max(0, rank), c.size() - 1)];
+    if (want_waves > 0) {                                     // override `waves` picks the shape with that many waves
+        bool found = false;
+        for (const Shape& x : c) if (x.W == want_waves) { sh = x; found = true; break; }
+        if (!found) return FLUTE_ERR_SHAPE;
+    }
+    const int units = N / 4, upw = sh.W / sh.KW;
+    if (units % upw) return FLUTE_ERR_SHAPE;
+    if (((size_t)N * (size_t)(K >> lg)) * 2 >= (size_t)0xfffffff0u || (size_t)units * K * 2 >= ((size_t)1 << 40)) return FLUTE_ERR_SHAPE;
+    (void)num_sms;
+    memset(p, 0, sizeof(*p));
+    p->family = 0;
+    p->m_block = 1; p->waves = sh.W; p->kw = sh.KW; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)(units / upw); p->block = (unsigned)(sh.W * 64);
+    p->lds_bytes = fast_lds_bytes(sh.W, sh.KW, sh.D, lg); p->lut_copies = 32;
+    p->ring_depth = sh.D; p->visits = 1; p->k_chunks = 1; p->one_shot = 4;
+    if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->lkw = ilog2(sh.KW); oa->upw = upw; oa->pk = sh.D; oa->depth = sh.D; oa->pipe = 1; }
     return FLUTE_OK;
 }
 
@@ -698,12 +737,31 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         if (want < 0 && bits == 4) { const int q = template_id % 4; want = (q == 3) ? 0 : ((q == 1 || q == 2) ? 1 : -1); }
         if (want < 0 && bits != 4) want = (t.sms_multiple == 2) ? 0 : (t.sms_multiple == 4 ? 1 : -1);
         bool taken = false;
+        // lean one-row kernel (qgemm_fast.h): by override (one_shot = 4), or automatically for the ids whose last digit leaves the choice
+        // to the planner and whose Stages digit asks for the planner's first or second shape (4-bit QuantMapMode digit 0, Stages 2 / 3,
+        // SMs_Multiple 1: ids 0 / 4 - TileP 64 - and 16 / 20 - TileP 32), on K = 2048 / 4096 layers up to 48 M weights that give at
+        // least half the CUs a workgroup - measured against the persistent and the round-4 one-shot kernel (us, persistent / lean /
+        // one-shot): 4096^2 4.42 / 4.05 / 4.14, 5120 4.96 / 4.90 / 5.88, 8192 5.51 / 5.46 / 5.91, 11008 7.54 / 6.86 / 8.04; not taken:
+        // 14336 7.85 / 8.27 / 8.43, 28672 13.6 / 13.9 / 14.6, more than three workgroups per CU (16384 x 2048: 5.97 against 5.49 on the
+        // one-shot kernel; 8192 x 2048 3.77 / 4.05 is taken), K = 8192 (8192^2 8.42 against 10.42, 4096 x 8192 5.71 / 5.97: by
+        // override only); never for a call that fuses the Hadamard rotation
+        if ((want == 4 || (want < 0 && bits == 4 && (template_id % 4) == 0 && t.stages <= 3 && t.sms_multiple == 1 && ov.waves < 0)) &&
+            !ov.had8 && ov.kw < 0) {
+            flute_plan q;
+            memset(&q, 0, sizeof(q));
+            if (plan_fast(bits, lg, M, N, K, num_sms, std::max(0, t.stages - 2), want == 4 ? ov.waves : -1, &q, oa) == FLUTE_OK &&
+                (want == 4 || (K != 8192 && (size_t)N * K <= ((size_t)48 << 20) && (long)q.grid * 2 >= (long)num_sms && (long)q.grid <= 3L * num_sms))) {
+                *p = q;
+                taken = true;
+            }
+        }
+        if (want == 4 && !taken) want = -1;
         // persistent one-shot kernel: by override, or automatically (one or two rows; four rows measured 1.7x the one-row
         // time - no faster than the MFMA kernel, profiles/r03/decode_lab_persist_rows.jsonl) on layers of >= 40 M weights that give
         // every CU six whole unit rows (below that the in-workgroup K split of the other two kernels wins:
         // profiles/r03/persist_lab.txt)
-        const bool persist_auto = want < 0 && persist_auto_ok(M);
-        if (want == 2 || persist_auto) {
+        const bool persist_auto = !taken && want < 0 && persist_auto_ok(M);
+        if (!taken && (want == 2 || persist_auto)) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
             if (plan_persist(bits, lg, M, N, K, num_sms, t, ovd, &q, oa) == FLUTE_OK) { *p = q; taken = true; }
@@ -921,7 +979,7 @@ int ensure_lds(const void* fn, size_t bytes) {
 // fused only up to 8192 elements (or when the caller forces the decode family: tests, A/B runs).
 bool hadamard_worth_fusing(int M, int K, bool forced) { return forced || (size_t)M * K <= 8192; }
 bool hadamard_fusable(const flute_plan& p, int hadamard_size, int M, int K, bool forced) {
-    return p.family == 0 && hadamard_size >= 2 && hadamard_size <= 512 &&
+    return p.family == 0 && p.one_shot != 4 && hadamard_size >= 2 && hadamard_size <= 512 &&
            (hadamard_size & (hadamard_size - 1)) == 0 && K % hadamard_size == 0 && hadamard_worth_fusing(M, K, forced);
 }
 
@@ -1080,6 +1138,26 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &nvis, &D, &hs, &nwg};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
             hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
+
+    if (p.family == 0 && p.one_shot == 4) {
+        FastKernel fn = fast_kernel_b4(dtype, t.tile_p, p.waves, p.kw, p.ring_depth);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        int lg = oa.lg;
+        uint64_t* stamps = nullptr;
+#ifdef FLUTE_STAMPS
+        if (workspace && workspace_bytes >= kXwgFlagBytes + (size_t)p.grid * p.waves * 128)
+            stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
+#endif
+        void* kargs[] = {&q32, &S, &A, &qm2, &D, &N, &lg, &stamps};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             return FLUTE_ERR_LAUNCH;
         }
@@ -1250,6 +1328,11 @@ int flute_debug_stream_read(const void* src, void* sink, size_t bytes, int bytes
     if (!src || !sink || bytes_per_wave < 8192 || bytes_per_wave % 8192) return FLUTE_ERR_SHAPE;
     return stream_read_dispatch(src, sink, bytes, bytes_per_wave, grid, block,
                                 reinterpret_cast<hipStream_t>(stream));
+}
+
+int flute_debug_timestamp(void* dst, void* stream) {
+    if (!dst) return FLUTE_ERR_NULL;
+    return timestamp_dispatch(dst, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -47,6 +47,12 @@ template <> struct Num<F16> {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a),
                                       __builtin_bit_cast(h2_t, b), c, false);
     }
+    // the same with a zero accumulator as an inline constant (hipcc otherwise zeroes the register first: v_mov + v_dot2c)
+    static __device__ __forceinline__ float dot2z(uint32_t a, uint32_t b) {
+        float r;
+        asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     static __device__ __forceinline__ uint16_t from_float(float f) {
         _Float16 h = (_Float16)f;
         return __builtin_bit_cast(uint16_t, h);
@@ -68,6 +74,11 @@ template <> struct Num<BF16> {
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a),
                                                __builtin_bit_cast(b2_t, b), c, false);
+    }
+    static __device__ __forceinline__ float dot2z(uint32_t a, uint32_t b) {
+        float r;
+        asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+        return r;
     }
     static __device__ __forceinline__ uint16_t from_float(float f) {
         __bf16 h = (__bf16)f;

@@ -20,6 +20,9 @@ OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pip
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had, int pipe);
+// lean one-row decode kernel (qgemm_fast.h): 4 bits, K = 512 * depth * kw; waves per workgroup, waves per unit row, pieces per wave
+typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
+FastKernel fast_kernel_b4(int dtype, int tile_p, int waves, int kw, int depth);
 // persistent one-shot decode kernel (qgemm_persist.h): mb rows per pass (1/2), depth = pieces per segment, nsets = register sets
 typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
 PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int nsets, int had);
@@ -49,6 +52,7 @@ int unpack_dispatch(int num_bits, int tile_p, int N, int K, const void* Q, void*
                     hipStream_t stream);
 int stream_read_dispatch(const void* src, void* sink, size_t bytes, int bytes_per_wave, int grid,
                          int block, hipStream_t stream);
+int timestamp_dispatch(void* dst, hipStream_t stream);
 int splitk_reduce_dispatch(int dtype, const float* partial, void* D, size_t mn, int splitk,
                            hipStream_t stream);
 

@@ -98,4 +98,15 @@ int stream_read_dispatch(const void* src, void* sink, size_t bytes, int bytes_pe
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
+// Measurement only: one lane writes the chip-wide 100 MHz clock (s_memrealtime) to *dst.  Captured into a hipGraph in front
+// of and behind the timed launches, the difference brackets exactly those launches (bench.py): HIP events around a graph
+// replay add a fixed 16 - 19 us per replay (profiles/r05/graph_replay_fixed_cost_probe.json).
+__global__ void timestamp_kernel(unsigned long long* dst) {
+    if (threadIdx.x == 0) *dst = (unsigned long long)wall_clock64();
+}
+int timestamp_dispatch(void* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned long long*>(dst));
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
 }  // namespace flute_amd

@@ -86,7 +86,10 @@ __device__ __forceinline__ u32x2_t lds_hidden64(uint32_t addr) {
 // 3 bits: k-pair word ww x fields (0..7 | 8..15).  The lookups of group g+1 - and, on a piece boundary, its
 // activation / scale reads (hidden) - are issued before the dot products of group g; LDS returns in order, so "at
 // most NEXT_READS younger operations outstanding" releases group g.
-template <typename T, int BITS, int MB, int D, int YB>
+// BA = 1 (qgemm_fast.h, 4 bits): the 8 table addresses of a group are all computed BEFORE its first lookup is issued (hipcc otherwise
+// alternates v_perm / ds_read through one address register: every lookup then waits for the VALU result it was just handed - visible
+// with ONE wave per SIMD, where nothing else fills the slot)
+template <typename T, int BITS, int MB, int D, int YB, int BA = 0>
 __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::NPLANES], uint32_t x_lane, uint32_t x_pshift,
                                                  uint32_t x_row, uint32_t s_lane, uint32_t s_piece, uint32_t lane_off,
                                                  float (&acc)[Layout<BITS>::J][MB]) {
@@ -117,7 +120,16 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
                 for (int c = 0; c < J / 8; ++c) sq4[I & 1][c] = lds_hidden128(sa + 16u * c);
             }
         }
-        if constexpr (BITS == 4) {
+        if constexpr (BITS == 4 && BA != 0) {
+            uint32_t ad[8];
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ad[ww * 4 + j] = __builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + j) << 8));
+            asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]), "+v"(ad[4]), "+v"(ad[5]), "+v"(ad[6]), "+v"(ad[7]));
+#pragma unroll
+            for (int n = 0; n < 8; ++n) v[g & 1][n] = lds_lookup32(ad[n]);
+        } else if constexpr (BITS == 4) {
 #pragma unroll
             for (int ww = 0; ww < 2; ++ww)
 #pragma unroll
@@ -161,7 +173,7 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
         // what was issued behind group g: the next group's 8 lookups and, on a piece boundary, its MB + ceil(J / 8) reads
         constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? MB + (J + 7) / 8 : 0) : 0;
         wait_group(g_tag, std::integral_constant<int, (NEXT_READS < 15 ? NEXT_READS : 15)>{});
-        if constexpr (GI == 0) {
+        if constexpr (GI == 0 && !(BITS == 4 && BA != 0)) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -173,7 +185,11 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) al[j][m] = NT::dot2(v[g & 1][ww * 4 + j], xq[I & 1][m][2 * GI + ww], al[j][m]);
+                    for (int m = 0; m < MB; ++m) {
+                        // (BA: a piece's first products start its partial sums - no register zeroed first)
+                        if (BA != 0 && GI == 0 && ww == 0) al[j][m] = NT::dot2z(v[g & 1][ww * 4 + j], xq[I & 1][m][2 * GI + ww]);
+                        else al[j][m] = NT::dot2(v[g & 1][ww * 4 + j], xq[I & 1][m][2 * GI + ww], al[j][m]);
+                    }
         } else if constexpr (BITS == 2) {
 #pragma unroll
             for (int ww = 0; ww < 2; ++ww)

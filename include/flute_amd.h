@@ -189,6 +189,10 @@ int flute_get_template_info(int num_bits, int template_id, flute_template_info* 
 int flute_debug_stream_read(const void* src, void* sink, size_t bytes, int bytes_per_wave,
                             int grid, int block, void* stream);
 
+/* Measurement only: enqueue a one-lane kernel that writes the chip-wide 100 MHz clock (ticks of 10 ns) to the
+ * 8 bytes at `dst` (device memory).  Capturable into a hipGraph: two of them bracket exactly the launches between. */
+int flute_debug_timestamp(void* dst, void* stream);
+
 const char* flute_strerror(int status);
 int flute_abi_version(void);
 

@@ -168,11 +168,19 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.one_shot == 3 and p.ring_depth == 2 and p.grid * p.waves * p.visits >= 28672 // 16
     rc, p = plan(1, 8192, 8192, bits=3, tid=4)               # 512 unit rows: too few for a wave per row
     assert rc == 0 and p.one_shot != 3
-    # layers up to 64 M weights: the one-shot kernel (qgemm_oneshot.h); 4096^2 has 8 pieces per unit row: a wave
-    # takes all 8 (no cross-wave reduction), every wave is full -> the software-pipelined loop (one_shot 2)
+    # layers up to 64 M weights: the one-shot kernels.  4096^2 has 8 pieces per unit row: a wave takes all 8 (no cross-wave
+    # reduction).  Round 5: one row of a 4-bit layer with K = 2048 / 4096 / 8192 takes the lean kernel (qgemm_fast.h,
+    # one_shot 4) under the automatic ids (QuantMapMode digit 0, Stages 2 / 3: first / second shape); the other digits keep the
+    # round-4 one-shot kernel they were tuned on (digit 1: 4 pieces per wave, software-pipelined loop, one_shot 2)
     rc, p = plan(1, 4096, 4096)
-    assert rc == 0 and p.family == 0 and p.one_shot == 2 and p.visits == 1 and p.waves % p.kw == 0
+    assert rc == 0 and p.family == 0 and p.one_shot == 4 and p.visits == 1 and p.waves % p.kw == 0
     assert (p.waves, p.kw, p.ring_depth, p.grid, p.block) == (4, 1, 8, 256, 256) and p.lds_bytes <= 80 * 1024
+    rc, p = plan(1, 4096, 4096, tid=20)
+    assert rc == 0 and p.one_shot == 4 and (p.waves, p.kw, p.ring_depth, p.grid, p.block) == (8, 2, 4, 256, 512)
+    rc, p = plan(1, 4096, 4096, tid=18)
+    assert rc == 0 and p.family == 0 and p.one_shot == 2 and (p.waves, p.kw, p.ring_depth, p.grid, p.block) == (4, 1, 8, 256, 256)
+    rc, p = plan(1, 4096, 4096, bits=2, tid=0)
+    assert rc == 0 and p.one_shot in (1, 2)
     lib = _lib.get()
     q = _lib.Plan()
     for (M, bits, g, N, K, tid) in ((1, 4, 64, 4096, 4480, 16), (2, 4, 128, 11008, 4096, 0), (4, 2, 64, 4096, 4096, 4),
@@ -245,6 +253,8 @@ def test_plan_invariants_over_random_shapes():
         bits = rng.choice([4, 4, 2, 3])
         tids = [t for (b, t), c in sorted(TEMPLATE_CONFIGS.items()) if b == bits and (bits != 3 or c["TileP"] == 32)]
         tid = rng.choice(tids)
+        if bits == 4 and rng.random() < 0.2:                  # the automatic ids (QuantMapMode digit 0, Stages 2 / 3, SMs_Multiple 1) more often
+            tid = rng.choice([0, 4, 16, 20])
         tile_p = TEMPLATE_CONFIGS[(bits, tid)]["TileP"]
         g = rng.choice([32, 64, 128, 256])
         J = 16 if bits == 3 else 16 // bits
@@ -273,6 +283,11 @@ def test_plan_invariants_over_random_shapes():
             elif p.one_shot in (1, 2):                            # one-shot kernel
                 assert p.visits == 1 and p.splitk == 1 and (K // g) % 2 == 0 and g >= 64, what
                 assert p.grid == -(-units // (p.waves // p.kw)) and -(-(-(-K // 512)) // p.kw) <= p.ring_depth, what
+            elif p.one_shot == 4:                                 # lean one-row kernel (qgemm_fast.h's host contract)
+                assert bits == 4 and M == 1 and g >= 64 and K in (2048, 4096, 8192) and 512 * p.ring_depth * p.kw == K, what
+                assert p.waves in (4, 8) and p.grid * (p.waves // p.kw) == N // 4, what
+                assert p.lds_bytes == 65536 + 2 * K + p.waves * 4 * p.ring_depth * (512 // g) * 2 + 128 + 16 * p.waves, what
+                assert tid % 4 == 0, what                         # automatic only for the ids whose last digit leaves the choice to the planner
             else:
                 assert p.ring_depth in (2, 4), what
         elif p.family == 5:                                       # skinny MFMA kernel
@@ -301,7 +316,7 @@ def test_plan_invariants_over_random_shapes():
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
             assert p.m_block != 4 or bits != 3 or p.lds_bytes == 146 * 1024, what
     # the sweep reaches every kernel of the library
-    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (2, 0), (3, 0), (5, 0), (6, 0)):
+    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 0), (3, 0), (5, 0), (6, 0)):
         assert fams.get(key, 0) > 0, (key, fams)
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the bench command (run on the GPU box): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in their own PMC passes (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE x2 correction on gfx950).
-# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r04_bench_traffic.json - the file bench.py
+# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r05_bench_traffic.json - the file bench.py
 # reads `roofline.traffic` from (copy it to profiles/; it carries the plan it was measured on and bench.py
 # drops it the moment the live plan differs).
 set -u
@@ -35,13 +35,20 @@ for l in summ.splitlines():
         m = re.search(r"WRITE_SIZE=(\d+)", l)
         if m: write = int(m.group(1))
 trace = [l for l in summ.splitlines() if l.startswith("TRACE ") and "qgem" in l]
+avg_ns = med_ns = ncalls = None
+for l in trace:
+    m = re.search(r"n=(\d+) min=\d+ med=(\d+) avg=([\d.]+)", l)
+    if m and (ncalls is None or int(m.group(1)) > ncalls):
+        ncalls, med_ns, avg_ns = int(m.group(1)), int(m.group(2)), float(m.group(3))
 rec = {"source": "tools/prof_bench.sh: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                  "separate passes over `" + cmd + "`",
        "kernel": kern, "workload": line["config"]["workload"], "plan": line["config"]["plan"],
        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
        "correction": "gfx950: FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled",
        "hbm_bytes_per_launch": None if fetch is None else (2 * fetch + (write or 0)) * 1024,
-       "kernel_trace": trace, "bench_untraced_ms_per_step": line["ms_per_step"]}
-json.dump(rec, open(out + "/r04_bench_traffic.json", "w"), indent=1)
+       "kernel_trace": trace, "kernel_trace_calls": ncalls, "kernel_us_rocprof_avg": None if avg_ns is None else round(avg_ns / 1e3, 4),
+       "kernel_us_rocprof_median": None if med_ns is None else round(med_ns / 1e3, 4),
+       "bench_untraced_ms_per_step": line["ms_per_step"]}
+json.dump(rec, open(out + "/r05_bench_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY

@@ -17,7 +17,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
                                          r.get("VGPR_Count"), r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
     for k, v in d.items():
         ds = sorted(x[0] for x in v)
-        lines.append(f"TRACE {k} n={len(ds)} min={ds[0]} med={ds[len(ds)//2]} max={ds[-1]} ns vgpr={v[0][1]} lds={v[0][2]} grid={v[0][3]} wg={v[0][4]}")
+        lines.append(f"TRACE {k} n={len(ds)} min={ds[0]} med={ds[len(ds)//2]} avg={sum(ds) / len(ds):.1f} max={ds[-1]} ns vgpr={v[0][1]} lds={v[0][2]} grid={v[0][3]} wg={v[0][4]}")
 for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in glob.glob(os.path.join(out, p, "**", "*counter_collection.csv"), recursive=True):
         acc = defaultdict(lambda: defaultdict(list))

@@ -42,7 +42,7 @@ with open(a.out, "a") as f:
         us = min(bench.time_graph(lay, steps, 3, torch.cuda.synchronize)[0] for _ in range(3)) / steps * 1e3
         rec = {"tag": a.tag, "bits": bits, "M": M, "N": N, "K": K, "dtype": dt, "ovr": ",".join(ov), "tid": tid, "us": round(us, 2),
                "TFLOPs": round(2.0 * M * N * K / us / 1e6, 1),
-               "plan": {k: plan[k] for k in ("family", "m_block", "m_tiles", "splitk", "grid")}}
+               "plan": {k: plan[k] for k in ("family", "one_shot", "waves", "kw", "ring_depth", "m_block", "m_tiles", "splitk", "grid")}}
         print(json.dumps(rec), flush=True)
         f.write(json.dumps(rec) + "\n")
         del lay

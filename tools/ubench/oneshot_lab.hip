@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "qgemm_oneshot.h"
+#include "qgemm_fast.h"
 
 using namespace flute_amd;
 
@@ -164,28 +165,11 @@ int main(int argc, char** argv) {
     const int units = N / 4, npieces = (K + 511) / 512;
     const double bytes = 2.0 * (N / 4) * K + 2.0 * N * G + 2.0 * M * K + 2.0 * M * N + 32 + 1024;
 
-#define V(name, D_, X_, OPT_, W_, kw_) Variant{name, (OneKernel)qgemv_oneshot_kernel<F16, 4, 32, 1, D_, X_, false, OPT_>, W_, kw_, 0, D_}
-    std::vector<Variant> vs = {
-        V("w4_kw1_d8_pipe_nt", 8, 2, 17, 4, 1), V("w4_kw1_d8_pipe_nt_il", 8, 2, 49, 4, 1), V("w4_kw1_d8_nolookup", 8, 2, 2, 4, 1), V("w4_kw1_d8_nolookup_il", 8, 2, 34, 4, 1),
-        V("w8_kw2_d4_pipe_nt", 4, 1, 17, 8, 2), V("w8_kw2_d4_pipe_nt_il", 4, 1, 49, 8, 2),
-        V("w4_kw2_d4_pipe_nt", 4, 2, 17, 4, 2), V("w4_kw2_d4_pipe_nt_il", 4, 2, 49, 4, 2),
-        V("w8_kw1_d8_pipe_nt", 8, 1, 17, 8, 1), V("w8_kw1_d8_pipe_nt_il", 8, 1, 49, 8, 1),
-        V("w8_kw4_d2_pipe_nt_il", 2, 1, 49, 8, 4), V("w16_kw4_d4_nt_il", 4, 1, 33, 16, 4),
-    };
-    for (auto& v : vs) {
-        const int pk = (npieces + v.kw - 1) / v.kw;
-        if (pk > v.depth) { printf("{\"variant\": \"%s\", \"skip\": \"pk %d > depth\"}\n", v.name, pk); continue; }
-        const int upw = v.W / v.kw, lkw = (int)log2((double)v.kw);
-        const int ipw = (32 + v.W - 1) / v.W;
-        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, ipw, 0, oneshot_x_in_holes(4, 1, K) ? 1 : 0);
-        const int grid = (units + upw - 1) / upw;
-        const int KX = npieces * 512;
-        const size_t lds = oneshot_lds_bytes(4, 1, v.depth, lg, K, v.W); (void)KX;
-        CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        auto launch = [&](int c) {
-            hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.W * 64), lds, st, d.Q + (size_t)c * d.qwords, (const void*)(d.S + (size_t)c * d.swords),
-                               (const void*)d.X, d.T2, K, N, geo, M, (void*)(d.D + (size_t)c * M * N), 1.0f, (uint64_t*)nullptr);
-        };
+    const char* mode = argc > 5 ? argv[5] : "all";              // all | fast (round 5: the lean kernel next to the shipped one) | floors
+    const bool run_old = strcmp(mode, "all") == 0, run_fast = strcmp(mode, "all") == 0 || strcmp(mode, "fast") == 0;
+    // check one launch against the CPU restatement, (stamps build: one stamped HBM-cold launch,) then time the graph
+    auto check_and_time = [&](const char* name, int W, int kw, int pk, int grid, size_t lds, const std::function<void(int, uint64_t*)>& launch_s) {
+        auto launch = [&](int c) { launch_s(c, nullptr); };
         CK(hipMemsetAsync(d.D, 0xff, (size_t)M * N * 2, st));
         launch(0);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
@@ -200,11 +184,11 @@ int main(int argc, char** argv) {
         const double rel = sqrt(num / den);
 #ifdef FLUTE_STAMPS
         {   // one stamped launch on a copy the graph replays have pushed out of the caches
-            const int nw = grid * v.W;
+            const int nw = grid * W;
             uint64_t* dst; CK(hipMalloc(&dst, (size_t)nw * 128)); CK(hipMemset(dst, 0, (size_t)nw * 128));
             for (int c = 1; c < d.ncopy; ++c) launch(c);
             CK(hipStreamSynchronize(st));
-            hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.W * 64), lds, st, d.Q, (const void*)d.S, (const void*)d.X, d.T2, K, N, geo, M, (void*)d.D, 1.0f, dst);
+            launch_s(0, dst);
             CK(hipStreamSynchronize(st));
             std::vector<uint64_t> hs((size_t)nw * 16);
             CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost)); CK(hipFree(dst));
@@ -214,21 +198,78 @@ int main(int argc, char** argv) {
             for (int w = 0; w < nw; ++w) {
                 const uint64_t* h = &hs[(size_t)w * 16];
                 st0.push_back((double)(h[0] - t0) / 100.0); en.push_back((double)(h[13] - t0) / 100.0);
-                for (int i = 0; i < 11; ++i) ph[i].push_back((double)(h[2 + i] - h[1]));
+                for (int i = 0; i < 11; ++i) if (h[2 + i]) ph[i].push_back((double)(h[2 + i] - h[1]));     // (helper waves leave at the barrier: no later stamps)
             }
             const char* names[11] = {"issued", "table_word", "table_written", "x_arrived", "x_written", "barrier", "scales_written", "pieces_done", "wave_reduced", "stored", "store_acked"};
-            printf("{\"stamps\": \"%s\", \"start_us\": [%.2f, %.2f, %.2f], \"end_us\": [%.2f, %.2f, %.2f]", v.name, qt(st0, .5), qt(st0, .9), qt(st0, 1.), qt(en, .5), qt(en, .9), qt(en, 1.));
-            for (int i = 0; i < 11; ++i) printf(", \"%s\": [%.0f, %.0f]", names[i], qt(ph[i], .5), qt(ph[i], .9));
+            printf("{\"stamps\": \"%s\", \"start_us\": [%.2f, %.2f, %.2f], \"end_us\": [%.2f, %.2f, %.2f]", name, qt(st0, .5), qt(st0, .9), qt(st0, 1.), qt(en, .5), qt(en, .9), qt(en, 1.));
+            for (int i = 0; i < 11; ++i) if (!ph[i].empty()) printf(", \"%s\": [%.0f, %.0f, %.0f]", names[i], qt(ph[i], .1), qt(ph[i], .5), qt(ph[i], .9));
+            // the late half of the grid (workgroups that start after the median): their phases decide the end of the launch
+            std::vector<double> late[11];
+            const double med = qt(st0, .5);
+            for (int w = 0; w < nw; ++w) if (st0[w] > med) for (int i = 0; i < 11; ++i) if (hs[(size_t)w * 16 + 2 + i]) late[i].push_back((double)(hs[(size_t)w * 16 + 2 + i] - hs[(size_t)w * 16 + 1]));
+            if (!late[0].empty()) { printf(", \"late_half_p50\": ["); for (int i = 0; i < 11; ++i) printf("%s%.0f", i ? ", " : "", late[i].empty() ? -1.0 : qt(late[i], .5)); printf("]"); }
             printf("}\n");
         }
 #endif
         const double us = time_graph(st, d.ncopy, 8, launch);
         printf("{\"variant\": \"%s\", \"tag\": \"%s\", \"N\": %d, \"K\": %d, \"g\": %d, \"W\": %d, \"kw\": %d, \"pk\": %d, \"grid\": %d, \"lds\": %zu, \"rel_err\": %.3e, \"nbad\": %d, \"us\": %.3f, \"GBps\": %.1f}\n",
-               v.name, tag, N, K, g, v.W, v.kw, pk, grid, lds, rel, nbad, us, bytes / us / 1e3);
+               name, tag, N, K, g, W, kw, pk, grid, lds, rel, nbad, us, bytes / us / 1e3);
         fflush(stdout);
+    };
+#define V(name, D_, X_, OPT_, W_, kw_) Variant{name, (OneKernel)qgemv_oneshot_kernel<F16, 4, 32, 1, D_, X_, false, OPT_>, W_, kw_, 0, D_}
+    std::vector<Variant> vs = {V("w4_kw1_d8_pipe_nt_il", 8, 2, 49, 4, 1), V("w4_kw1_d8_nolookup_il", 8, 2, 34, 4, 1)};
+    if (run_old) {
+        std::vector<Variant> more = {
+            V("w4_kw1_d8_pipe_nt", 8, 2, 17, 4, 1), V("w4_kw1_d8_nolookup", 8, 2, 2, 4, 1),
+            V("w8_kw2_d4_pipe_nt", 4, 1, 17, 8, 2), V("w8_kw2_d4_pipe_nt_il", 4, 1, 49, 8, 2),
+            V("w4_kw2_d4_pipe_nt", 4, 2, 17, 4, 2), V("w4_kw2_d4_pipe_nt_il", 4, 2, 49, 4, 2),
+            V("w8_kw1_d8_pipe_nt", 8, 1, 17, 8, 1), V("w8_kw1_d8_pipe_nt_il", 8, 1, 49, 8, 1),
+            V("w8_kw4_d2_pipe_nt_il", 2, 1, 49, 8, 4), V("w16_kw4_d4_nt_il", 4, 1, 33, 16, 4),
+        };
+        vs.insert(vs.end(), more.begin(), more.end());
+    }
+    if (strcmp(mode, "floors") == 0) vs.clear();
+    for (auto& v : vs) {
+        const int pk = (npieces + v.kw - 1) / v.kw;
+        if (pk > v.depth) { printf("{\"variant\": \"%s\", \"skip\": \"pk %d > depth\"}\n", v.name, pk); continue; }
+        const int upw = v.W / v.kw, lkw = (int)log2((double)v.kw);
+        const int ipw = (32 + v.W - 1) / v.W;
+        const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, ipw, 0, oneshot_x_in_holes(4, 1, K) ? 1 : 0);
+        const int grid = (units + upw - 1) / upw;
+        const size_t lds = oneshot_lds_bytes(4, 1, v.depth, lg, K, v.W);
+        CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        check_and_time(v.name, v.W, v.kw, pk, grid, lds, [&](int c, uint64_t* stamps) {
+            hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.W * 64), lds, st, d.Q + (size_t)c * d.qwords, (const void*)(d.S + (size_t)c * d.swords),
+                               (const void*)d.X, d.T2, K, N, geo, M, (void*)(d.D + (size_t)c * M * N), 1.0f, stamps);
+        });
+    }
+    // round 5: the lean kernel (qgemm_fast.h): K = 512 * D * KW is a compile-time constant
+    if (run_fast) {
+        typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
+        struct FV { const char* name; FastKernel fn; int W, kw, depth, H; bool xh; };
+#define FV_(name, W_, KW_, D_, H_, OPT_) FV{name, (FastKernel)qgemv_fast_kernel<F16, 32, W_, KW_, D_, H_, OPT_>, W_, KW_, D_, H_, ((OPT_) & 8) != 0}
+        const FV fvs[] = {
+            FV_("fast_w4_kw1_d8", 4, 1, 8, 0, 0), FV_("fast_w8_kw2_d4", 8, 2, 4, 0, 0), FV_("fast_w4_kw2_d4", 4, 2, 4, 0, 0),
+            FV_("fast_w4_kw1_d8_run2", 4, 1, 8, 0, 96), FV_("fast_w8_kw2_d4_run2", 8, 2, 4, 0, 96),
+            FV_("fast_w4_kw1_d8_nolookup", 4, 1, 8, 0, 2),
+            FV_("fast_w8_kw2_d8", 8, 2, 8, 0, 0), FV_("fast_w16_kw4_d4", 16, 4, 4, 0, 0),
+            FV_("fast_w4_kw1_d4", 4, 1, 4, 0, 0), FV_("fast_w8_kw2_d2", 8, 2, 2, 0, 0),
+        };
+        for (const FV& v : fvs) {
+            if (512 * v.depth * v.kw != K) continue;
+            const int upw = v.W / v.kw;
+            if (units % upw) continue;
+            const int grid = units / upw;
+            const size_t lds = fast_lds_bytes(v.W, v.kw, v.depth, lg, v.xh);
+            CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            check_and_time(v.name, v.W + v.H, v.kw, v.depth, grid, lds, [&](int c, uint64_t* stamps) {
+                hipLaunchKernelGGL(v.fn, dim3(grid), dim3((v.W + v.H) * 64), lds, st, d.Q + (size_t)c * d.qwords, (const void*)(d.S + (size_t)c * d.swords),
+                                   (const void*)d.X, d.T2, (void*)(d.D + (size_t)c * M * N), N, lg, stamps);
+            });
+        }
     }
     // round-2 one-shot kernel (qgemm_stream.h), the plan the round-2 tuner took for the headline: 8 waves, kw 2
-    if (units % 4 == 0 && units / 4 <= 512 && npieces <= 8) {
+    if (run_old && units % 4 == 0 && units / 4 <= 512 && npieces <= 8) {
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.M = M; sa.N = N; sa.K = K; sa.G = G; sa.lg = lg; sa.units = units; sa.upw = 4; sa.kw = 2; sa.lkw = 1;
@@ -256,7 +297,7 @@ int main(int argc, char** argv) {
                tag, N, K, sa.nwg, lds, sqrt(num / den), us, bytes / us / 1e3);
         fflush(stdout);
     }
-    {   // dispatch ramp: when does each wave of an (otherwise empty) grid start?
+    if (run_old) {   // dispatch ramp: when does each wave of an (otherwise empty) grid start?
         const int cfg[][3] = {{256, 256, 0}, {256, 512, 0}, {256, 512, 76 * 1024}, {512, 256, 0}, {1024, 256, 0}, {256, 1024, 0}, {512, 512, 0}, {128, 512, 0}, {2048, 64, 0}, {1024, 128, 0}};
         CK(hipFuncSetAttribute((const void*)ramp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (auto& c : cfg) {
