@@ -226,7 +226,9 @@ int plan_oneshot(int bits, int lg, int M, int N, int K, int num_sms, const flute
 // on 4096 x 4096, 7.49 / 7.50 against 8.63 on 4096 x 11008; K = 8192: (8, 2, 8) 6.50 on 8192 x 4096 (g = 128).  rank = the
 // template's Stages - 2.
 int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int want_waves, flute_plan* p, OneArgs* oa) {
-    if (bits != 4 || M != 1 || lg < 6 || lg > 8) return FLUTE_ERR_SHAPE;
+    if (bits != 4 || M < 1 || M > 4 || lg < 6 || lg > 8) return FLUTE_ERR_SHAPE;
+    int mb = 1; while (mb < M) mb <<= 1;                       // rows per pass: 1, 2, 4 (their activations beside the table image: mb * K * 2 <= 32 KB)
+    if ((size_t)mb * K * 2 > 32768) return FLUTE_ERR_SHAPE;
     struct Shape { int W, KW, D; };
     std::vector<Shape> c;
     if (K == 2048) c = {{4, 1, 4}};
@@ -250,9 +252,9 @@ int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int 
     (void)num_sms;
     memset(p, 0, sizeof(*p));
     p->family = 0;
-    p->m_block = 1; p->waves = sh.W; p->kw = sh.KW; p->splitk = 1; p->k_per_split = K;
+    p->m_block = mb; p->waves = sh.W; p->kw = sh.KW; p->splitk = 1; p->k_per_split = K;
     p->grid = (unsigned)(units / upw); p->block = (unsigned)(sh.W * 64);
-    p->lds_bytes = fast_lds_bytes(sh.W, sh.KW, sh.D, lg); p->lut_copies = 32;
+    p->lds_bytes = fast_lds_bytes(sh.W, sh.KW, sh.D, lg, mb); p->lut_copies = 32;
     p->ring_depth = sh.D; p->visits = 1; p->k_chunks = 1; p->one_shot = 4;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->lkw = ilog2(sh.KW); oa->upw = upw; oa->pk = sh.D; oa->depth = sh.D; oa->pipe = 1; }
     return FLUTE_OK;
@@ -744,13 +746,17 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // one-shot): 4096^2 4.42 / 4.05 / 4.14, 5120 4.96 / 4.90 / 5.88, 8192 5.51 / 5.46 / 5.91, 11008 7.54 / 6.86 / 8.04; not taken:
         // 14336 7.85 / 8.27 / 8.43, 28672 13.6 / 13.9 / 14.6, more than three workgroups per CU (16384 x 2048: 5.97 against 5.49 on the
         // one-shot kernel; 8192 x 2048 3.77 / 4.05 is taken), K = 8192 (8192^2 8.42 against 10.42, 4096 x 8192 5.71 / 5.97: by
-        // override only); never for a call that fuses the Hadamard rotation
+        // override only).  Two to four rows (dot products per row on the same lookups): while ONE round of workgroups covers the layer
+        // (4096^2: M = 2 5.04 -> 4.29 us, M = 3, 4 6.25 -> 5.03; 4096 x 2048: 3.87 -> 3.25, 4.65 -> 3.71; beyond, the persistent kernel
+        // (M = 2) and the skinny MFMA kernel (M = 3, 4) win: 8192 x 4096 5.79 against 7.12, 8.69 against 8.98).  Never for a call that
+        // fuses the Hadamard rotation
         if ((want == 4 || (want < 0 && bits == 4 && (template_id % 4) == 0 && t.stages <= 3 && t.sms_multiple == 1 && ov.waves < 0)) &&
             !ov.had8 && ov.kw < 0) {
             flute_plan q;
             memset(&q, 0, sizeof(q));
             if (plan_fast(bits, lg, M, N, K, num_sms, std::max(0, t.stages - 2), want == 4 ? ov.waves : -1, &q, oa) == FLUTE_OK &&
-                (want == 4 || (K != 8192 && (size_t)N * K <= ((size_t)48 << 20) && (long)q.grid * 2 >= (long)num_sms && (long)q.grid <= 3L * num_sms))) {
+                (want == 4 || (K != 8192 && (size_t)N * K <= ((size_t)48 << 20) && (long)q.grid * 2 >= (long)num_sms &&
+                               (long)q.grid <= (M == 1 ? 3L : 1L) * num_sms))) {
                 *p = q;
                 taken = true;
             }
@@ -1145,7 +1151,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
 
     if (p.family == 0 && p.one_shot == 4) {
-        FastKernel fn = fast_kernel_b4(dtype, t.tile_p, p.waves, p.kw, p.ring_depth);
+        FastKernel fn = fast_kernel_b4(dtype, t.tile_p, p.waves, p.kw, p.ring_depth, p.m_block);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
@@ -1156,7 +1162,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         if (workspace && workspace_bytes >= kXwgFlagBytes + (size_t)p.grid * p.waves * 128)
             stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
 #endif
-        void* kargs[] = {&q32, &S, &A, &qm2, &D, &N, &lg, &stamps};
+        void* kargs[] = {&q32, &S, &A, &qm2, &D, &N, &lg, &M, &stamps};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             return FLUTE_ERR_LAUNCH;

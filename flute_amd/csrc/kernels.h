@@ -20,9 +20,9 @@ OneKernel oneshot_kernel_b4_bf16(int tile_p, int mb, int depth, int had, int pip
 OneKernel oneshot_kernel_b2_f16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b2_bf16(int tile_p, int mb, int depth, int had, int pipe);
 OneKernel oneshot_kernel_b3(int dtype, int tile_p, int mb, int depth, int had, int pipe);
-// lean one-row decode kernel (qgemm_fast.h): 4 bits, K = 512 * depth * kw; waves per workgroup, waves per unit row, pieces per wave
-typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
-FastKernel fast_kernel_b4(int dtype, int tile_p, int waves, int kw, int depth);
+// lean decode kernel (qgemm_fast.h): 4 bits, K = 512 * depth * kw; waves per workgroup, waves per unit row, pieces per wave, rows per pass (1/2/4)
+typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, int, uint64_t*);
+FastKernel fast_kernel_b4(int dtype, int tile_p, int waves, int kw, int depth, int mb);
 // persistent one-shot decode kernel (qgemm_persist.h): mb rows per pass (1/2), depth = pieces per segment, nsets = register sets
 typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
 PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int nsets, int had);

@@ -221,6 +221,38 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
     });
 }
 
+// Transpose-reduce of a 4-bit wave's partial sums (round 5): acc[4 columns][MB rows] per lane -> ONE sum per (column, row),
+// left in `v` of the HOLDER lanes (lane & 3 = column, row = my_m): 22 instructions at MB = 1 where four wave_sum64 take 44.
+// Quad: a lane keeps column (lane & 1) of each column pair and hands the other to its neighbour, then the same between the
+// pairs - every lane of a quad ends with the quad's sum of column lane & 3 (9 instructions per row).  The four 16-lane DPP
+// rows: v_permlane32_swap a, b exchanges a's upper half with b's lower half, so a + b holds row-pair sums of a in the lower
+// half and of b in the upper; v_permlane16_swap does the same between odd and even rows.  MB = 1: both with copies of the value
+// (plain sums); MB = 2: activation row m in half m; MB = 4: DPP row r holds activation row {0, 2, 1, 3}[r].  Last, inside a
+// DPP row: row_ror 4 / 8 (the rotation keeps lane & 3).
+template <int MB>
+__device__ __forceinline__ void transpose_reduce4(const float (&acc)[4][MB], int lane, float& v, int& my_m, bool& holder) {
+    auto dpp_add = [](float keep, float send, auto ctrl_tag) {
+        return keep + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), decltype(ctrl_tag)::value, 0xF, 0xF, true));
+    };
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+    float kq[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const float k01 = dpp_add(o1 ? acc[1][m] : acc[0][m], o1 ? acc[0][m] : acc[1][m], std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+        const float k23 = dpp_add(o1 ? acc[3][m] : acc[2][m], o1 ? acc[2][m] : acc[3][m], std::integral_constant<int, 0xB1>{});
+        kq[m] = dpp_add(o2 ? k23 : k01, o2 ? k01 : k23, std::integral_constant<int, 0x4E>{});                                     // quad_perm [2,3,0,1]
+    }
+    auto swap32_add = [](float a, float b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); return a + b; };
+    auto swap16_add = [](float a, float b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); return a + b; };
+    static_assert(MB == 1 || MB == 2 || MB == 4, "rows per pass");
+    if constexpr (MB == 1) { v = swap16_add(kq[0], kq[0]); v = swap32_add(v, v); my_m = 0; }
+    else if constexpr (MB == 2) { v = swap32_add(kq[0], kq[1]); v = swap16_add(v, v); my_m = lane >> 5; }
+    else { const float ab = swap32_add(kq[0], kq[1]), cd = swap32_add(kq[2], kq[3]); v = swap16_add(ab, cd); my_m = ((lane >> 4) & 1) * 2 + (lane >> 5); }
+    v = dpp_add(v, v, std::integral_constant<int, 0x124>{});                                                                      // row_ror:4
+    v = dpp_add(v, v, std::integral_constant<int, 0x128>{});                                                                      // row_ror:8
+    holder = (lane & (MB == 1 ? 63 : (MB == 2 ? 31 : 15))) < 4;   // lanes 0..3 of the first DPP row that holds the activation row
+}
+
 // OPT bits (development / A-B measurements, tools/ubench/oneshot_lab.hip): 1 = nt on the weight loads,
 // 2 = ablate the lookups (timing floor: stream + prologue only), 8 = wait for every piece before the first
 // lookup (round-2 behaviour), 16 = software-pipelined lookup groups (every wave of the launch must hold D pieces),

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
     float acc[J][MB];
     uint16_t* Dout = reinterpret_cast<uint16_t*>(Dp);
     // one segment from register set `set`: its scale image, its D pieces, and - on a unit's last chunk - the outputs
-    auto do_seg = [&](auto set_tag, int v, int c) {
+    auto do_seg = [&](auto set_tag, int v_idx, int c) {
+        const int v = v_idx;
         constexpr int set = decltype(set_tag)::value;
         const uint32_t simg = sbase + (uint32_t)set * s_wave_bytes;
 #pragma unroll
@@ -218,9 +219,20 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
 #pragma unroll
                 for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
         }
-        pipelined_pieces<T, BITS, MB, D, AHEAD>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, x_row,
-                                             simg + (uint32_t)(gl * J) * 2u, s_piece, lane_off, acc);
-        if (c == nch - 1) {
+        pipelined_pieces<T, BITS, MB, D, AHEAD, (BITS == 4) ? 1 : 0>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, x_row,
+                                                                  simg + (uint32_t)(gl * J) * 2u, s_piece, lane_off, acc);
+        if constexpr (BITS == 4) {
+            // round 5: the unit's 4 x MB sums reduced together, one store instruction (qgemm_oneshot.h: transpose_reduce4)
+            if (c == nch - 1) {
+                float v;
+                int my_m;
+                bool holder;
+                transpose_reduce4<MB>(acc, lane, v, my_m, holder);
+                const int unit = unit_of(v_idx);
+                if (holder && my_m < M && v_idx < nvis && unit < units)
+                    Dout[(size_t)my_m * N + unit_col0<BITS, TILEP>(unit) + (lane & 3) * TILEP] = NT::from_float(v);
+            }
+        } else if (c == nch - 1) {
             float tot[J][MB];
 #pragma unroll
             for (int j = 0; j < J; ++j)

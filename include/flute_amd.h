@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define FLUTE_AMD_ABI_VERSION 5
+/* 6 (round 5): flute_plan.one_shot / flute_overrides.one_shot value 4 (lean decode kernel, qgemm_fast.h), flute_debug_timestamp */
+#define FLUTE_AMD_ABI_VERSION 6
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -95,7 +96,9 @@ typedef struct flute_plan {
                             non-persistent workgroups, every request issued by the prologue, ring_depth = pieces per
                             wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
                             (qgemm_persist.h: table / activations staged once, every wave walks `visits` units of
-                            `k_chunks` segments of ring_depth pieces, the next segment requested ahead) */
+                            `k_chunks` segments of ring_depth pieces, the next segment requested ahead), 4 = lean decode
+                            kernel (qgemm_fast.h, round 5: 4 bits, M <= 4, K = 512 * ring_depth * kw in {2048, 4096, 8192}
+                            a compile-time constant, m_block rows per pass) */
     int splitk_mode;     /* splitk > 1: 0 = fp32 slabs in the workspace + a second (reduce) launch, 1 = combined inside the
                             launch (csrc/xwg.h: write-through slabs + one arrival word per output tile) */
 } flute_plan;
@@ -117,7 +120,8 @@ typedef struct flute_plan {
  *   ring_depth      decode: pieces in flight per wave (ring kernel 2/4; one-shot kernel 4/8, 3-bit 2/4); without
  *                   one_shot = 1 a given depth selects the ring kernel
  *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 3 persistent one-shot kernel (M <= 2) - the code
- *                   flute_plan.one_shot reports for it; 2, ABI v4's value for the same request, is still accepted */
+ *                   flute_plan.one_shot reports for it; 2, ABI v4's value for the same request, is still accepted; 4 lean decode
+ *                   kernel (4 bits, M <= 4, K in {2048, 4096, 8192}; `waves` 4 / 8 picks its shape; what it cannot take falls back) */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;

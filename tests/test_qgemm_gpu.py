@@ -306,12 +306,13 @@ def test_persistent_oneshot_kernel(env):
     assert plan["one_shot"] == 3 and plan["waves"] * plan["grid"] <= 8 * env.num_sms, plan
 
 
-def test_lean_one_row_kernel(env):
-    """The lean one-row decode kernel (qgemm_fast.h, round 5; plan.one_shot == 4; override one_shot = 4, automatic for the
-    automatic 4-bit ids on K = 2048 / 4096 / 8192 layers in the one-shot regime): every instantiated shape (waves per
-    workgroup, waves per unit row, pieces per wave) x dtype x TileP x group size - against the oracle, one-hot rows
-    bit-exact (the identity contract of tests/kernel.py:30-36), an arbitrary pair codebook (HIGGS vector_size = 2: table2
-    is not an outer product) included.  What it does not take falls back to the round-4 kernels."""
+def test_lean_decode_kernel(env):
+    """The lean decode kernel (qgemm_fast.h, round 5; plan.one_shot == 4; override one_shot = 4, automatic for the
+    automatic 4-bit ids on K = 2048 / 4096 layers in the one-shot regime): every instantiated shape (waves per
+    workgroup, waves per unit row, pieces per wave) x rows per pass (M = 1 .. 4) x dtype x TileP x group size - against
+    the oracle, one-hot rows bit-exact (the identity contract of tests/kernel.py:30-36), an arbitrary pair codebook
+    (HIGGS vector_size = 2: table2 is not an outer product) included.  What it does not take falls back to the round-4
+    kernels."""
     from flute_amd import dev
     d = env.dev
     cases = [
@@ -320,14 +321,12 @@ def test_lean_one_row_kernel(env):
         (64, 256, torch.float16, 4096, 1024, 1), (32, 128, torch.bfloat16, 8192, 1024, 0), (64, 64, torch.float16, 8192, 512, 0),
         (32, 256, torch.bfloat16, 2048, 1024, 0), (64, 64, torch.float16, 2048, 2048, 0), (32, 64, torch.bfloat16, 4096, 11008 // 128 * 128, 1),
     ]
+    ran = {1: 0, 2: 0, 4: 0}
     for (tile_p, g, dtype, K, N, rank) in cases:
         bits = 4
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 83 + N % 11 + rank)
         tid = template_ids_for(env.fa, bits, tile_p)[0] + 4 * rank          # Stages 2 + rank, QuantMapMode digit 0
-        ovr = dev.Overrides(one_shot=4)
-        plan = dev.get_plan(1, N, K, bits, g, tid, env.num_sms, dtype, ovr)
-        assert plan["family"] == 0 and plan["one_shot"] == 4, plan
-        assert 512 * plan["ring_depth"] * plan["kw"] == K and plan["grid"] * (plan["waves"] // plan["kw"]) == N // 4, plan
+        ovr = dev.Overrides(family=0, one_shot=4)
         Qd, Sd, td = Q.to(d), S.to(d), table.to(d)
         for pair_codebook in (False, True):
             t2 = table2
@@ -335,24 +334,38 @@ def test_lean_one_row_kernel(env):
                 grid = torch.randn(256, 2).to(dtype)
                 t2 = grid.view(16, 16, 2).contiguous().view(torch.float32)          # [16, 16, 1]: two T in a 32-bit container
             What = env.O.dequantize(Q.numpy(), S, t2, bits, g, tile_p).float()
-            X = (torch.randn(1, K) / 100).to(dtype)
-            out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
-            assert rel_err(out, X.float() @ What) < tol_of(dtype), (tile_p, g, dtype, K, N, rank, pair_codebook)
-            for k in (0, K - 1, int(torch.randint(0, K, (1,)))):
-                E = torch.zeros(1, K, dtype=dtype)
-                E[0, k] = 1
+            for M in (1, 2, 3, 4):
+                mb = 1 if M == 1 else (2 if M == 2 else 4)
+                plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
+                if mb * K * 2 > 32768:                                      # the rows do not fit beside the table image: a round-4 kernel
+                    assert plan["one_shot"] != 4 or plan["family"] != 0, (M, K, plan)
+                    continue
+                assert plan["family"] == 0 and plan["one_shot"] == 4 and plan["m_block"] == mb, plan
+                assert 512 * plan["ring_depth"] * plan["kw"] == K and plan["grid"] * (plan["waves"] // plan["kw"]) == N // 4, plan
+                ran[mb] += 1
+                X = (torch.randn(M, K) / 100).to(dtype)
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert out.shape == (M, N)
+                assert rel_err(out, X.float() @ What) < tol_of(dtype), (tile_p, g, dtype, K, N, rank, M, pair_codebook)
+                ks = torch.randint(0, K, (M,))
+                ks[0] = (0, K - 1)[M % 2]
+                E = torch.zeros(M, K, dtype=dtype)
+                E[torch.arange(M), ks] = 1
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
-                assert torch.equal(out1.float(), What[k:k + 1].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, k, pair_codebook)
-        # the automatic plan of the same id is this kernel while the layer is in the one-shot regime
+                assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, pair_codebook)
+        # the automatic plan of the same id is this kernel for one row while the layer is in the one-shot regime
+        plan1 = dev.get_plan(1, N, K, bits, g, tid, env.num_sms, dtype, ovr)
         auto = dev.get_plan(1, N, K, bits, g, tid, env.num_sms, dtype)
-        if N * K <= (48 << 20) and env.num_sms <= 2 * plan["grid"] <= 6 * env.num_sms and K != 8192:
+        if N * K <= (48 << 20) and env.num_sms <= 2 * plan1["grid"] <= 6 * env.num_sms and K != 8192:
             assert auto["one_shot"] == 4, auto
-    # not taken: two rows, 2 / 3 bits, 32-wide groups, K that is not 2048 / 4096 / 8192, a fused Hadamard rotation
-    t32 = template_ids_for(env.fa, 4, 32)[0]
-    for (M, K, bits, g) in ((2, 4096, 4, 64), (1, 4096, 2, 64), (1, 4096, 3, 64), (1, 4096, 4, 32), (1, 3584, 4, 64), (1, 14336, 4, 64)):
-        plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(one_shot=4))
-        assert plan["one_shot"] != 4, (M, K, bits, g, plan)
-    assert t32 == 16
+        auto4 = dev.get_plan(4, N, K, bits, g, tid, env.num_sms, dtype)
+        if N * K <= (16 << 20) and env.num_sms <= 2 * plan1["grid"] <= 2 * env.num_sms and K != 8192:      # one round of workgroups
+            assert auto4["family"] == 0 and auto4["one_shot"] == 4 and auto4["m_block"] == 4, auto4
+    assert min(ran.values()) > 0, ran
+    # not taken: five rows, 2 / 3 bits, 32-wide groups, K that is not 2048 / 4096 / 8192
+    for (M, K, bits, g) in ((5, 4096, 4, 64), (1, 4096, 2, 64), (1, 4096, 3, 64), (1, 4096, 4, 32), (1, 3584, 4, 64), (1, 14336, 4, 64)):
+        plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=0, one_shot=4) if M <= 4 else dev.Overrides(one_shot=4))
+        assert plan["one_shot"] != 4 or plan["family"] != 0, (M, K, bits, g, plan)
 
 
 def test_skinny_mfma_kernel(env):

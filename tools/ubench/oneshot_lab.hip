@@ -245,13 +245,12 @@ int main(int argc, char** argv) {
     }
     // round 5: the lean kernel (qgemm_fast.h): K = 512 * D * KW is a compile-time constant
     if (run_fast) {
-        typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
+        typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, int, uint64_t*);
         struct FV { const char* name; FastKernel fn; int W, kw, depth, H; bool xh; };
-#define FV_(name, W_, KW_, D_, H_, OPT_) FV{name, (FastKernel)qgemv_fast_kernel<F16, 32, W_, KW_, D_, H_, OPT_>, W_, KW_, D_, H_, ((OPT_) & 8) != 0}
+#define FV_(name, W_, KW_, D_, H_, OPT_) FV{name, (FastKernel)qgemv_fast_kernel<F16, 32, W_, KW_, D_, 1, OPT_>, W_, KW_, D_, 0, false}
         const FV fvs[] = {
             FV_("fast_w4_kw1_d8", 4, 1, 8, 0, 0), FV_("fast_w8_kw2_d4", 8, 2, 4, 0, 0), FV_("fast_w4_kw2_d4", 4, 2, 4, 0, 0),
-            FV_("fast_w4_kw1_d8_run2", 4, 1, 8, 0, 96), FV_("fast_w8_kw2_d4_run2", 8, 2, 4, 0, 96),
-            FV_("fast_w4_kw1_d8_nolookup", 4, 1, 8, 0, 2),
+            FV_("fast_w4_kw1_d8_hipcc_order", 4, 1, 8, 0, 32), FV_("fast_w4_kw1_d8_nolookup", 4, 1, 8, 0, 2),
             FV_("fast_w8_kw2_d8", 8, 2, 8, 0, 0), FV_("fast_w16_kw4_d4", 16, 4, 4, 0, 0),
             FV_("fast_w4_kw1_d4", 4, 1, 4, 0, 0), FV_("fast_w8_kw2_d2", 8, 2, 2, 0, 0),
         };
@@ -260,11 +259,11 @@ int main(int argc, char** argv) {
             const int upw = v.W / v.kw;
             if (units % upw) continue;
             const int grid = units / upw;
-            const size_t lds = fast_lds_bytes(v.W, v.kw, v.depth, lg, v.xh);
+            const size_t lds = fast_lds_bytes(v.W, v.kw, v.depth, lg, 1);
             CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             check_and_time(v.name, v.W + v.H, v.kw, v.depth, grid, lds, [&](int c, uint64_t* stamps) {
                 hipLaunchKernelGGL(v.fn, dim3(grid), dim3((v.W + v.H) * 64), lds, st, d.Q + (size_t)c * d.qwords, (const void*)(d.S + (size_t)c * d.swords),
-                                   (const void*)d.X, d.T2, (void*)(d.D + (size_t)c * M * N), N, lg, stamps);
+                                   (const void*)d.X, d.T2, (void*)(d.D + (size_t)c * M * N), N, lg, M, stamps);
             });
         }
     }
