@@ -19,6 +19,7 @@
 #include "qgemm_stream.h"
 #include "qgemm_persist.h"
 #include "qgemm_fast.h"
+#include "qgemm_fastm.h"
 #include "qgemm_skinny.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
@@ -40,7 +41,8 @@ Ovr ovr_of(const flute_overrides* o) {
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
 constexpr int kFamilySkinny = 5;                // registers-only MFMA kernel for 3 <= M <= 32 (qgemm_skinny.h)
-constexpr int kFamilySplitK = 6;                // 128 x 128 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
+constexpr int kFamilySplitK = 6;
+constexpr int kFamilyFastM = 7;                 // lean MFMA decode kernel: 4 unit rows x all of K per workgroup, M <= 16 (qgemm_fastm.h)                // 128 x 128 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
 // Workspace layout (every kernel): [0, kXwgFlagBytes) tile state words of the in-launch reductions (xwg.h; zero between
 // calls), fp32 slabs behind them.  A planner sees the room behind the state words only.
 size_t slab_room(size_t workspace_bytes) { return workspace_bytes > kXwgFlagBytes ? workspace_bytes - kXwgFlagBytes : 0; }
@@ -257,6 +259,25 @@ int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int 
     p->lds_bytes = fast_lds_bytes(sh.W, sh.KW, sh.D, lg, mb); p->lut_copies = 32;
     p->ring_depth = sh.D; p->visits = 1; p->k_chunks = 1; p->one_shot = 4;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->lkw = ilog2(sh.KW); oa->upw = upw; oa->pk = sh.D; oa->depth = sh.D; oa->pipe = 1; }
+    return FLUTE_OK;
+}
+
+// Lean MFMA decode kernel (qgemm_fastm.h, round 5): 4 bits, M <= 16, K = 4096 (8 waves x 512 k) or 2048 (8 x 256 k), a workgroup =
+// 4 unit rows (16 columns) x all of K; every wave's K range must hold >= 2 groups (its scale words are read as whole dwords).
+int plan_fastm(int bits, int lg, int M, int N, int K, flute_plan* p, OneArgs* oa) {
+    if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 8 || (K != 4096 && K != 2048)) return FLUTE_ERR_SHAPE;
+    const int W = 8, nm = K / (128 * W);
+    if (((128 * nm) >> lg) < 2) return FLUTE_ERR_SHAPE;
+    const int units = N / 4;
+    if (units % 4) return FLUTE_ERR_SHAPE;
+    if (((size_t)N * (size_t)(K >> lg)) * 2 >= (size_t)0xfffffff0u || (size_t)units * K * 2 >= ((size_t)1 << 40)) return FLUTE_ERR_SHAPE;
+    memset(p, 0, sizeof(*p));
+    p->family = kFamilyFastM;
+    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = 1; p->waves = W; p->kw = W; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)(units / 4); p->block = (unsigned)(W * 64);
+    p->lds_bytes = fastm_lds_bytes(K); p->lut_copies = 32;
+    p->ring_depth = nm; p->visits = 1; p->k_chunks = 1; p->one_shot = 0;
+    if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = nm; }
     return FLUTE_OK;
 }
 
@@ -520,8 +541,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
               StreamArgs* sa, OneArgs* oa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
     // override families: -1 automatic, 0 decode, 1 / 2 per-wave MFMA kernel, 3 block kernels, 5 skinny MFMA kernel,
-    // 6 split-K block kernel; anything else is a caller error (round 1's family 4 is gone)
-    if (ov.family < -1 || ov.family == 4 || ov.family > 6) return FLUTE_ERR_SHAPE;
+    // 6 split-K block kernel, 7 lean MFMA decode kernel; anything else is a caller error (round 1's family 4 is gone)
+    if (ov.family < -1 || ov.family == 4 || ov.family > 7) return FLUTE_ERR_SHAPE;
     if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
     if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
     flute_template_info t;
@@ -571,6 +592,20 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // slabs per wave (4096 x 28672: 21.1 us against 23.3 here).  Measured (profiles/r03/skinny_lab.jsonl, M = 16, us, per-wave kernel -> skinny):
     // 4096 x 11008 17.9 -> 12.0, 4096 x 14336 18.3 -> 12.6 (M = 4: 17.6 -> 11.8), 4096 x 28672 26.6 -> 23.3, 4096 x 6144
     // 13.1 -> 11.7, 2048 x 8192 7.6 -> 7.0; 4096 x 8192 10.0 -> 11.8 and 4096^2 7.6 -> 11.6 (not taken).
+    // Lean MFMA decode kernel (qgemm_fastm.h, round 5): by override (family 7), or automatically for 5 <= M <= 16 rows of a 4-bit layer
+    // with K = 2048 / 4096 that ONE round of its workgroups (4 unit rows each) covers, under the ids whose last digit leaves the
+    // choice to the planner (QuantMapMode digit 0, SMs_Multiple 1).  Measured (tools/time_cases.py, us, automatic plan of round 4 ->
+    // this kernel; profiles/r05/time_cases_fastm*.jsonl): 4096^2 M = 5 / 8 / 16 7.13 / 7.13 / 7.18 -> 5.9 / 5.9 / 6.1, 4096 x 2048
+    // 5.7 / 5.7 / 5.8 -> 4.3 / 4.3 / 4.5, 2048 x 4096 7.6 / 7.6 / 7.7 -> 5.4 / 5.4 / 5.6; not taken: more than one round (8192 x 4096:
+    // 10.2 .. 10.8 against the skinny kernel's 8.9 .. 9.6: every workgroup pulls all of X through its CU), M <= 4 (the dot-product
+    // lean kernel: 5.05 against 5.9)
+    const bool fastm_auto = ov.family < 0 && bits == 4 && M >= 5 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 &&
+                            (K == 4096 || K == 2048) && (long)(N / 16) <= (long)num_sms && (long)(N / 16) * 2 >= (long)num_sms &&
+                            ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0;
+    if (ov.family == kFamilyFastM || fastm_auto) {
+        if (plan_fastm(bits, lg, M, N, K, p, oa) == FLUTE_OK) return FLUTE_OK;
+        memset(p, 0, sizeof(*p));
+    }
     {
         const int q4 = (bits == 4) ? template_id % 4 : -1;
         const long slabs5 = units / 16;
@@ -1144,6 +1179,25 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &nvis, &D, &hs, &nwg};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
             hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
+
+    if (p.family == kFamilyFastM) {
+        FastMKernel fn = fastm_kernel_b4(dtype, t.tile_p, p.waves, p.ring_depth, oa.lg);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        uint64_t* stamps = nullptr;
+#ifdef FLUTE_STAMPS
+        if (workspace && workspace_bytes >= kXwgFlagBytes + (size_t)p.grid * p.waves * 128)
+            stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + kXwgFlagBytes);
+#endif
+        void* kargs[] = {&q32, &S, &A, &qm2, &D, &N, &M, &stamps};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             return FLUTE_ERR_LAUNCH;
         }

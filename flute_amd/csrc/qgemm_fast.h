@@ -41,7 +41,6 @@ namespace flute_amd {
 __host__ __device__ constexpr size_t fast_lds_bytes(int W, int KW, int D, int lg, int mb = 1) {
     return (size_t)65536 + (size_t)mb * 512 * D * KW * 2 + (size_t)W * 4 * D * (512 >> lg) * 2 + 128 + (size_t)W * 64;
 }
-constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 
 // OPT bits (lab): 1 = default-policy weight loads (nt otherwise), 2 = lookups ablated (timing floor), 32 = hipcc's own
 // order of table addresses / lookups and zeroed partial sums (pipelined_pieces BA = 0)

@@ -27,6 +27,8 @@
 
 namespace flute_amd {
 
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+
 // launch geometry packed into one kernel-argument dword (preloaded)
 struct OneGeo {
     static constexpr uint32_t pack(int lg, int lkw, int upw, int pk, int ipw, int had_log, int xh) {

@@ -70,7 +70,12 @@ def test_plan_families_and_invariants():
                 want = 3                             # 3 bits: the per-wave kernel is slow enough that 128 blocks already win
             if bits != 3 and M == 1000:
                 want = 6                             # 2 / 4 bits: 8 x 32 tiles of 128 x 128, one per CU (qgemm_splitk.h, round 4)
+            if bits == 4 and 5 <= M <= 16:
+                want = 7                             # 4 bits, K = 4096, one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
+            if p.family == 7:
+                assert (p.grid, p.waves, p.block, p.lds_bytes, p.splitk, p.workspace_needed) == (256, 8, 512, 32768 + 32 * 4096, 1, 0)
+                continue
             if p.family == 6:
                 assert (p.grid, p.block, p.splitk, p.workspace_needed) == (256, 768, 1, 0)      # 8 compute + 4 loader waves
                 continue
@@ -220,8 +225,10 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 2 and (p.m_block, p.m_tiles, p.slabs_per_wave, p.grid) == (1, 1, 2, 224)
     rc, p = plan(16, 10240, 8192)                            # 160 slabs fill 62 % of the CUs: no lane sharing either
     assert rc == 0 and p.family == 2 and (p.m_block, p.slabs_per_wave, p.grid) == (1, 1, 160)
-    rc, p = plan(16, 4096, 4096)                             # 64 slabs: four lanes share a unit
-    assert rc == 0 and p.family == 2 and (p.m_block, p.grid) == (4, 256)
+    rc, p = plan(16, 4096, 4096)                             # one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
+    assert rc == 0 and p.family == 7 and p.grid == 256
+    assert _lib.get().flute_qgemm_plan_ex(0, 4, 64, 16, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(family=2), p) == 0
+    assert p.family == 2 and (p.m_block, p.grid) == (4, 256)   # the per-wave kernel there: 64 slabs, four lanes share a unit
     rc, p = plan(16, 4096, 4096, tid=19)                     # QuantMapMode digit 3 at M <= 16: skinny wherever it exists
     assert rc == 0 and p.family == 5 and p.grid == 64
     for (M, N, K, bits, tid) in ((16, 4096, 4096, 4, 16), (16, 20480, 4096, 4, 16), (16, 28672, 4096, 4, 16), (17, 14336, 4096, 4, 16), (2, 14336, 4096, 4, 16),
@@ -298,6 +305,9 @@ def test_plan_invariants_over_random_shapes():
                 assert p.splitk_mode == 1 and p.workspace_needed == p.splitk * (N // 64) * 4096 + 65536 and p.grid <= num_sms and K // p.splitk >= 2048, what
             else:
                 assert p.workspace_needed == 0, what
+        elif p.family == 7:                                       # lean MFMA decode kernel (qgemm_fastm.h's host contract)
+            assert bits == 4 and 5 <= M <= 16 and K in (2048, 4096) and g >= 64 and (K // 8) // g >= 2 and tid % 4 == 0, what
+            assert p.grid == N // 16 and p.grid <= num_sms and p.waves == 8 and p.lds_bytes == 32768 + 32 * K and p.ring_depth * 128 * 8 == K, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
@@ -316,7 +326,7 @@ def test_plan_invariants_over_random_shapes():
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
             assert p.m_block != 4 or bits != 3 or p.lds_bytes == 146 * 1024, what
     # the sweep reaches every kernel of the library
-    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 0), (3, 0), (5, 0), (6, 0)):
+    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 0), (3, 0), (5, 0), (6, 0), (7, 0)):
         assert fams.get(key, 0) > 0, (key, fams)
 
 

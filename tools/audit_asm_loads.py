@@ -25,7 +25,7 @@ CSRC = os.path.join(ROOT, "flute_amd", "csrc")
 UNITS = ["inst_stream_b4.hip", "inst_stream_b3.hip", "inst_stream_b2.hip", "inst_block_b4.hip", "inst_block_b2.hip", "inst_block_b3.hip",
          "inst_oneshot_b4_f16.hip", "inst_oneshot_b4_bf16.hip", "inst_oneshot_b2_f16.hip", "inst_oneshot_b2_bf16.hip", "inst_oneshot_b3.hip",
          "inst_oneshot_persist_b4.hip", "inst_oneshot_persist_b2.hip", "inst_oneshot_persist_b3.hip",
-         "inst_oneshot_skinny_b4.hip", "inst_oneshot_fast_b4.hip", "inst_splitk.hip"]
+         "inst_oneshot_skinny_b4.hip", "inst_oneshot_fast_b4.hip", "inst_oneshot_fastm_b4.hip", "inst_splitk.hip"]
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"^\s*(buffer_load_dword\w*|global_load_dword\w*|global_load_lds_\w+)\s+(\S+),")
