@@ -28,6 +28,10 @@
 //     t's four steps carry the four requests of macro-step t + 2, and the loop starts when macro-step 0's rows are in LDS
 //     (first version: all 16 requests up front - the wave's in-order issue stood in the addresser's queue for 2 800 .. 5 200
 //     cycles before its first lookup: 6.34 us at M = 16 on 4096^2, profiles/r05/stamps_fastm_run1.jsonl);
+//     Measured and dropped (profiles/r05/time_cases_fastm_run3_loader_waves_dropped.jsonl, stamps_fastm_run3.jsonl): four LOADER
+//     waves that do nothing but request the activations and write them to LDS, one workgroup barrier per macro-step - 6.11
+//     against 6.15 us: what bounds the kernel is not who issues the requests but the 128 KB of activations EVERY workgroup pulls
+//     from L2 (all 256 CUs read the same lines at once: ~32 B/clk per CU, 4 000 cycles at M = 16);
 //   * epilogue: a wave leaves its 16 x 16 partial tile in its own (no longer needed) activation region, one barrier, every
 //     wave sums 256 / W outputs over the W partial tiles in a fixed order and stores them.
 // Arithmetic contract: as the decode kernels (include/flute_amd.h): fp32 group scale on the group's partial sum.

@@ -407,7 +407,7 @@ def test_lean_mfma_decode_kernel(env):
                 assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, pair_codebook)
     # not taken (the override falls back): 17 rows, 2 / 3 bits, 32-wide groups, other K, one group per wave
     for (M, K, bits, g) in ((17, 4096, 4, 64), (8, 4096, 2, 64), (8, 4096, 3, 64), (8, 4096, 4, 32), (8, 8192, 4, 64), (8, 2048, 4, 256)):
-        plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, ovr)
+        plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=7))
         assert plan["family"] != 7, (M, K, bits, g, plan)
 
 
