@@ -418,7 +418,8 @@ def main():
                 lay = Layer(m, n, k, bits, g, dtype, device, copies_for(n, k, bits), NF4_VALUES)
                 lay.tune()
                 steps = 500 if m < 256 else (200 if m < 1024 else 60)
-                e_ms, _ = time_graph(lay, steps, 20, lambda: torch.cuda.synchronize())
+                # (best of two replays: one 200-step replay was once timed at twice its usual length on a fresh box)
+                e_ms = min(time_graph(lay, steps, 20, lambda: torch.cuda.synchronize())[0] for _ in range(2))
                 us = e_ms / steps * 1e3
                 mm = {}
                 if m >= 256:                                              # dense fp16 GEMM of the same shape beside it

@@ -143,6 +143,15 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
 #pragma unroll
                 for (int jp = 0; jp < 4; ++jp)
                     v[g & 1][ww * 4 + jp] = lds_lookup64(__builtin_amdgcn_perm(q[I][0][2 * GI + ww], lane_off, 0x0c0c0400u | ((4u + jp) << 8)));
+        } else if constexpr (BA != 0) {
+            constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
+            const uint32_t w[3] = {q[I][0][ww], q[I][1][ww], q[I][2][ww]};
+            uint32_t ad[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ad[j] = (field<3>(w, j0 + j) << 7) | lane_off;
+            asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]), "+v"(ad[4]), "+v"(ad[5]), "+v"(ad[6]), "+v"(ad[7]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g & 1][j] = lds_lookup32(ad[j]);
         } else {
             constexpr int ww = GI / 2, j0 = (GI % 2) * 8;
             const uint32_t w[3] = {q[I][0][ww], q[I][1][ww], q[I][2][ww]};
@@ -175,7 +184,7 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
         // what was issued behind group g: the next group's 8 lookups and, on a piece boundary, its MB + ceil(J / 8) reads
         constexpr int NEXT_READS = (g + 1 < NG * D) ? 8 + (((g + 1) % NG == 0) ? MB + (J + 7) / 8 : 0) : 0;
         wait_group(g_tag, std::integral_constant<int, (NEXT_READS < 15 ? NEXT_READS : 15)>{});
-        if constexpr (GI == 0 && !(BITS == 4 && BA != 0)) {
+        if constexpr (GI == 0 && !(BITS != 2 && BA != 0)) {
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -207,7 +216,10 @@ __device__ __forceinline__ void pipelined_pieces(ring16_t (&q)[D][Layout<BITS>::
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) al[j0 + j][m] = NT::dot2(v[g & 1][j], xq[I & 1][m][ww], al[j0 + j][m]);
+                for (int m = 0; m < MB; ++m) {
+                    if (BA != 0 && ww == 0) al[j0 + j][m] = NT::dot2z(v[g & 1][j], xq[I & 1][m][ww]);       // the piece's first k pair starts the partial sums
+                    else al[j0 + j][m] = NT::dot2(v[g & 1][j], xq[I & 1][m][ww], al[j0 + j][m]);
+                }
         }
         if constexpr (GI == NG - 1) {
 #pragma unroll
@@ -253,6 +265,41 @@ __device__ __forceinline__ void transpose_reduce4(const float (&acc)[4][MB], int
     v = dpp_add(v, v, std::integral_constant<int, 0x124>{});                                                                      // row_ror:4
     v = dpp_add(v, v, std::integral_constant<int, 0x128>{});                                                                      // row_ror:8
     holder = (lane & (MB == 1 ? 63 : (MB == 2 ? 31 : 15))) < 4;   // lanes 0..3 of the first DPP row that holds the activation row
+}
+
+// The same for a 3-bit unit's 16 columns: acc[16][MB] per lane -> one sum per (column, row); the holder of column j of row my_m is lane
+// (lane & 15) == j of the first DPP row that holds the activation row.  53 instructions at MB = 1 where sixteen wave_sum64 take 176.
+// Levels: lane pairs (column 2 p + (lane & 1) of every column pair), quads (column 4 r + (lane & 3)), the four quads of a DPP row
+// (a two-stage barrel shifter rotates the lane's four values by its quad index, row_ror 4 / 8 / 12 hands value k to the quad k
+// further on: every lane ends with column lane & 15 summed over its row), the four rows (lane-swap instructions, as above).
+template <int MB>
+__device__ __forceinline__ void transpose_reduce16(const float (&acc)[16][MB], int lane, float& v, int& my_m, bool& holder) {
+    static_assert(MB == 1 || MB == 2, "rows per pass");
+    auto dpp_add = [](float keep, float send, auto ctrl_tag) {
+        return keep + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), decltype(ctrl_tag)::value, 0xF, 0xF, true));
+    };
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0, q1 = (lane & 4) != 0, q2 = (lane & 8) != 0;
+    float vr[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        float k1[8], k2[4], s1[4], r[4];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) k1[p] = dpp_add(o1 ? acc[2 * p + 1][m] : acc[2 * p][m], o1 ? acc[2 * p][m] : acc[2 * p + 1][m], std::integral_constant<int, 0xB1>{});
+#pragma unroll
+        for (int c = 0; c < 4; ++c) k2[c] = dpp_add(o2 ? k1[2 * c + 1] : k1[2 * c], o2 ? k1[2 * c] : k1[2 * c + 1], std::integral_constant<int, 0x4E>{});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1[i] = q1 ? k2[(i + 1) & 3] : k2[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = q2 ? s1[(i + 2) & 3] : s1[i];                 // r[i] = k2[(quad + i) % 4]
+        float t = dpp_add(r[0], r[1], std::integral_constant<int, 0x124>{});             // row_ror:4: from the lane one quad back, whose r[1] is MY column
+        t = dpp_add(t, r[2], std::integral_constant<int, 0x128>{});
+        vr[m] = dpp_add(t, r[3], std::integral_constant<int, 0x12C>{});
+    }
+    auto swap32_add = [](float a, float b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); return a + b; };
+    auto swap16_add = [](float a, float b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); return a + b; };
+    if constexpr (MB == 1) { v = swap16_add(vr[0], vr[0]); v = swap32_add(v, v); my_m = 0; }
+    else { v = swap32_add(vr[0], vr[1]); v = swap16_add(v, v); my_m = lane >> 5; }
+    holder = (lane & (MB == 1 ? 63 : 31)) < 16;
 }
 
 // OPT bits (development / A-B measurements, tools/ubench/oneshot_lab.hip): 1 = nt on the weight loads,
@@ -598,7 +645,7 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
         // EVERY wave of the grid holds exactly D pieces (api.hip: plan_oneshot; a run-time fallback to the plain loop
         // would put two sets of counted waits on the same in-flight registers behind a branch, the arrangement hipcc
         // mis-schedules - measured: wrong results).
-        pipelined_pieces<T, BITS, MB, D, 0>(q, x_lane, x_pshift, x_row, s_lane, (uint32_t)(gpp * J) * 2u, lane_off, acc);
+        pipelined_pieces<T, BITS, MB, D, 0, (BITS != 2) ? 1 : 0>(q, x_lane, x_pshift, x_row, s_lane, (uint32_t)(gpp * J) * 2u, lane_off, acc);
     } else {
         // ---- pieces, each released by its own counted wait (loads return in order) ----
         [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -617,37 +664,64 @@ __global__ __launch_bounds__(oneshot_max_threads(BITS, MB)) void qgemv_oneshot_k
     auto store_out = [&](int j, int m, float v) {
         if (m < M && live) Dout[(size_t)m * N + col0 + j * TILEP] = NT::from_float(v);
     };
-    float tot[J][MB];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) tot[j][m] = wave_sum64(acc[j][m]);
-    FLUTE_OSTAMP(10);
-    if (kw == 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int j = 0; j < J; ++j) store_out(j, m, tot[j][m]);
+    constexpr bool TR = (BITS == 4) || (BITS == 3 && MB <= 2);      // round 5: the unit's J x MB sums reduced together (transpose_reduce4 / 16)
+    if constexpr (TR) {
+        float v;
+        int my_m;
+        bool holder;
+        if constexpr (BITS == 4) transpose_reduce4<MB>(acc, lane, v, my_m, holder);
+        else transpose_reduce16<(MB <= 2 ? MB : 1)>(reinterpret_cast<float (&)[16][MB <= 2 ? MB : 1]>(acc), lane, v, my_m, holder);
+        FLUTE_OSTAMP(10);
+        const int jh = lane & (J - 1);
+        if (kw == 1) {
+            if (holder) store_out(jh, my_m, v);                     // one store instruction per unit
+        } else {
+            float* rb = reinterpret_cast<float*>(smem + red_off) + 32;
+            if (holder) rb[wave * (J * MB) + jh * MB + my_m] = v;
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == kw - 1) {
+                for (int t = lane; t < J * MB; t += 64) {
+                    float sum = 0.f;
+                    for (int kp = 0; kp < kw; ++kp) sum += rb[(ul * kw + kp) * (J * MB) + t];
+                    store_out(t / MB, t % MB, sum);
+                }
+            }
         }
     } else {
-        // no barrier: every wave leaves its partial sums and an arrival tick in LDS, the last arriver sums and
-        // stores (release on the tick / acquire by the reader: the partials are ordered before it)
-        float* rb = reinterpret_cast<float*>(smem + red_off) + 32;
-        if (lane == 0) {
+        float tot[J][MB];
 #pragma unroll
-            for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) rb[wave * (J * MB) + j * MB + m] = tot[j][m];
-        }
-        int ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket == kw - 1) {
-            for (int t = lane; t < J * MB; t += 64) {
-                float sum = 0.f;
-                for (int kp = 0; kp < kw; ++kp) sum += rb[(ul * kw + kp) * (J * MB) + t];
-                store_out(t / MB, t % MB, sum);
+            for (int m = 0; m < MB; ++m) tot[j][m] = wave_sum64(acc[j][m]);
+        FLUTE_OSTAMP(10);
+        if (kw == 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) store_out(j, m, tot[j][m]);
+            }
+        } else {
+            // no barrier: every wave leaves its partial sums and an arrival tick in LDS, the last arriver sums and
+            // stores (release on the tick / acquire by the reader: the partials are ordered before it)
+            float* rb = reinterpret_cast<float*>(smem + red_off) + 32;
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) rb[wave * (J * MB) + j * MB + m] = tot[j][m];
+            }
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&arrive[ul], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == kw - 1) {
+                for (int t = lane; t < J * MB; t += 64) {
+                    float sum = 0.f;
+                    for (int kp = 0; kp < kw; ++kp) sum += rb[(ul * kw + kp) * (J * MB) + t];
+                    store_out(t / MB, t % MB, sum);
+                }
             }
         }
     }

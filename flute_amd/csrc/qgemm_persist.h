@@ -219,18 +219,19 @@ __global__ __launch_bounds__(512) void qgemv_persist_kernel(
 #pragma unroll
                 for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
         }
-        pipelined_pieces<T, BITS, MB, D, AHEAD, (BITS == 4) ? 1 : 0>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, x_row,
+        pipelined_pieces<T, BITS, MB, D, AHEAD, (BITS != 2) ? 1 : 0>(q[set], x_lane0 + ((uint32_t)(c * D) << x_pshift), x_pshift, x_row,
                                                                   simg + (uint32_t)(gl * J) * 2u, s_piece, lane_off, acc);
-        if constexpr (BITS == 4) {
-            // round 5: the unit's 4 x MB sums reduced together, one store instruction (qgemm_oneshot.h: transpose_reduce4)
+        if constexpr (BITS != 2) {
+            // round 5: the unit's J x MB sums reduced together, one store instruction (qgemm_oneshot.h: transpose_reduce4 / 16)
             if (c == nch - 1) {
                 float v;
                 int my_m;
                 bool holder;
-                transpose_reduce4<MB>(acc, lane, v, my_m, holder);
+                if constexpr (BITS == 4) transpose_reduce4<MB>(acc, lane, v, my_m, holder);
+                else transpose_reduce16<MB>(acc, lane, v, my_m, holder);
                 const int unit = unit_of(v_idx);
                 if (holder && my_m < M && v_idx < nvis && unit < units)
-                    Dout[(size_t)my_m * N + unit_col0<BITS, TILEP>(unit) + (lane & 3) * TILEP] = NT::from_float(v);
+                    Dout[(size_t)my_m * N + unit_col0<BITS, TILEP>(unit) + (lane & (J - 1)) * TILEP] = NT::from_float(v);
             }
         } else if (c == nch - 1) {
             float tot[J][MB];
