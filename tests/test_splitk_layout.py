@@ -121,7 +121,7 @@ def test_plan_family6():
     assert _plan(256, 4096, 4096, g=256, family=6, splitk=16)[0] != 0
     rc, p = _plan(200, 11008, 4096, family=6, m_tiles=8)
     assert rc == 0 and p.grid == 2 * 86 * p.splitk
-    assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=7)[0] != 0   # unknown families are refused
+    assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=8)[0] != 0   # unknown families are refused (7 = the lean MFMA decode kernel since round 5: falls back above M = 16)
 
 
 def test_xcd_pair_order_is_a_bijection():
