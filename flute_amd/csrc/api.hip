@@ -234,6 +234,7 @@ int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int 
     struct Shape { int W, KW, D; };
     std::vector<Shape> c;
     if (K == 2048) c = {{4, 1, 4}};
+    else if (K == 3584) c = {{4, 1, 7}};                       // (Gemma-2-9B: 7 pieces per wave)
     else if (K == 4096) {
         // one round of workgroups (<= one per CU): a wave per unit row, no cross-wave sum (4096^2: 4.05 us against 4.16 with
         // 8 waves); more rounds: two waves per SIMD hide each other's stalls (11008: 6.86 against 6.97, 5120: 4.90 / 5.15,

@@ -29,7 +29,7 @@
 // (flute/csrc/qgemm_kernel.hpp:546-557, :617-712), Stream-K fix-up replaced by the in-workgroup K split
 // (tile_scheduler_utils.hpp:58-211).
 //
-// Host contract (api.hip: plan_fast): num_bits = 4, 1 <= M <= MB in {1, 2, 4}, K == 512 * D * KW, units = N / 4 a
+// Host contract (api.hip: plan_fast): num_bits = 4, 1 <= M <= MB in {1, 2, 4}, K == 512 * D * KW (D = 1 .. 8: K = 3584 is D = 7), units = N / 4 a
 // multiple of W / KW, group size in {64, 128, 256}, MB * K * 2 <= 32768, N * (K / g) * 2 < 4 GiB.
 // LDS: [table image 64 KB][activations MB x K][W scale images of 4 columns x D * (512 / g) groups][arrival counters +
 // K-split partials].
@@ -44,12 +44,17 @@ __host__ __device__ constexpr size_t fast_lds_bytes(int W, int KW, int D, int lg
 
 // OPT bits (lab): 1 = default-policy weight loads (nt otherwise), 2 = lookups ablated (timing floor), 32 = hipcc's own
 // order of table addresses / lookups and zeroed partial sums (pipelined_pieces BA = 0)
+// (The fused Hadamard pre-rotation of flute.qgemm_hadamard stays with the round-4 one-shot kernel: this kernel's four waves rotate
+// a row of K = 3584 / 4096 in two rounds - measured with the rotation as a template flag, 4.69 / 4.62 us against 4.81 / 4.61 for one
+// row on 4096 x 3584 / 4096 x 4096 and 6.28 against 5.99 for two: profiles/r05/call20_hadamard.log - and the flag was removed.)
 template <typename T, int TILEP, int W, int KW, int D, int MB = 1, int OPT = 0>
 __global__ __launch_bounds__(W * 64) void qgemv_fast_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
-    const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int lg, int M, uint64_t* __restrict__ stamps) {
+    const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int lg, int M,
+    uint64_t* __restrict__ stamps) {
     using NT = Num<T>;
     constexpr int K = 512 * D * KW;
+    constexpr bool POW2 = (D & (D - 1)) == 0;                       // K a power of two: groups per column and per wave are shifts
     constexpr int LK = ilog2_c(K);
     constexpr int UPW = W / KW;                                     // unit rows per workgroup
     constexpr int ENT = 256 / W;                                    // table entries a wave loads and replicates
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(W * 64) void qgemv_fast_kernel(
     constexpr uint32_t S_BASE = X_BASE + (uint32_t)MB * K * 2u;
     static_assert(W == 4 || W == 8 || W == 16, "waves per workgroup");
     static_assert(MB == 1 || MB == 2 || MB == 4, "rows per pass");
-    static_assert((KW & (KW - 1)) == 0 && (D & (D - 1)) == 0 && W % KW == 0, "power-of-two split");
+    static_assert((KW & (KW - 1)) == 0 && D >= 1 && D <= 8 && W % KW == 0, "K split: a power of two; 1 .. 8 pieces per wave");
     static_assert(MB * K * 2 <= 32768, "activation rows");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,16 +102,21 @@ __global__ __launch_bounds__(W * 64) void qgemv_fast_kernel(
         xv[r] = buf_load16((XP % (W * 64) == 0 || pidx < XP) ? (uint32_t)pidx * 16u : 0x80000000u, x_srd, 0);
     }
     // scale words: lane q = lane + 64 r holds groups (2 gp, 2 gp + 1) of column j of this wave's K range, q = j * (gpw / 2) + gp
-    const int lgh = (8 + ilog2_c(D)) - lg;                          // log2(groups of the wave's range / 2)
-    const int lG = LK - lg;                                         // log2(G)
-    const srd_t s_srd = make_srd(Sp, (uint32_t)((size_t)N << (lG + 1)));
+    const int lgh = (8 + ilog2_c(D)) - lg;                          // POW2: log2(groups of the wave's range / 2)
+    const int lG = LK - lg;                                         // POW2: log2(G)
+    const int G = K >> lg;
+    const int gpw2 = (D * (512 >> lg)) >> 1;                        // group pairs of the wave's range (7 pieces: 28 / 14 / 7)
+    // (q / gpw2 with the three possible divisors as compile-time constants: no integer division in the prologue)
+    auto col_of = [&](int q) { return POW2 ? (q >> lgh) : (lg == 6 ? q / (D * 4) : (lg == 7 ? q / (D * 2) : q / D)); };
+    const srd_t s_srd = make_srd(Sp, (uint32_t)((size_t)N * (size_t)G * 2));
     uint32_t sv[NSL];
 #pragma unroll
     for (int r = 0; r < NSL; ++r) {
         const int q = lane + 64 * r;
-        const int j = q >> lgh;
-        const int gp = q & ((1 << lgh) - 1);
-        const uint32_t vo = (uint32_t)((((col0 + j * TILEP) << lG) + (kpart << (lgh + 1)) + 2 * gp) * 2);
+        const int j = col_of(q);
+        const int gp = POW2 ? (q & ((1 << lgh) - 1)) : (q - j * gpw2);
+        const uint32_t vo = POW2 ? (uint32_t)((((col0 + j * TILEP) << lG) + (kpart << (lgh + 1)) + 2 * gp) * 2)
+                                 : (uint32_t)(((col0 + j * TILEP) * G + kpart * 2 * gpw2 + 2 * gp) * 2);
         sv[r] = buf_load4_at(j < 4 ? vo : 0x80000000u, s_srd, 0);
     }
     const srd_t q_srd = make_srd(Qp + (size_t)unit * (K / 2), (uint32_t)K * 2u);
@@ -141,8 +151,9 @@ __global__ __launch_bounds__(W * 64) void qgemv_fast_kernel(
         vm_wait_regs<XPR - 1 - r + NSL + D>(xv[r]);
         if constexpr (r == 0) { FLUTE_FSTAMP(5); }
         const int pidx = (r * W + wave) * 64 + lane;
-        if (XP % (W * 64) == 0 || pidx < XP)
+        if (XP % (W * 64) == 0 || pidx < XP) {                      // wave-uniform: a round of a wave is 64 whole pieces
             *reinterpret_cast<uint4*>(smem + X_BASE + (uint32_t)pidx * 16u) = make_uint4(xv[r].x, xv[r].y, xv[r].z, xv[r].w);
+        }
     });
     FLUTE_FSTAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -155,8 +166,8 @@ __global__ __launch_bounds__(W * 64) void qgemv_fast_kernel(
     for (int r = 0; r < NSL; ++r) {
         vm_wait_regs<D>(sv[r]);
         const int qq = lane + 64 * r;
-        const int j = qq >> lgh;
-        const int gp = qq & ((1 << lgh) - 1);
+        const int j = col_of(qq);
+        const int gp = POW2 ? (qq & ((1 << lgh) - 1)) : (qq - j * gpw2);
         if (j < 4) {
             uint16_t* img = reinterpret_cast<uint16_t*>(smem + sbase) + (2 * gp) * 4 + j;
             img[0] = (uint16_t)(sv[r] & 0xffffu);

@@ -291,7 +291,7 @@ def test_plan_invariants_over_random_shapes():
                 assert p.visits == 1 and p.splitk == 1 and (K // g) % 2 == 0 and g >= 64, what
                 assert p.grid == -(-units // (p.waves // p.kw)) and -(-(-(-K // 512)) // p.kw) <= p.ring_depth, what
             elif p.one_shot == 4:                                 # lean one-row kernel (qgemm_fast.h's host contract)
-                assert bits == 4 and M <= p.m_block <= 4 and g >= 64 and K in (2048, 4096, 8192) and 512 * p.ring_depth * p.kw == K, what
+                assert bits == 4 and M <= p.m_block <= 4 and g >= 64 and K in (2048, 3584, 4096, 8192) and 512 * p.ring_depth * p.kw == K, what
                 assert p.waves in (4, 8) and p.grid * (p.waves // p.kw) == N // 4 and p.m_block * K * 2 <= 32768, what
                 assert p.lds_bytes == 65536 + p.m_block * 2 * K + p.waves * 4 * p.ring_depth * (512 // g) * 2 + 128 + 64 * p.waves, what
                 assert tid % 4 == 0, what                         # automatic only for the ids whose last digit leaves the choice to the planner

@@ -320,6 +320,7 @@ def test_lean_decode_kernel(env):
         (32, 64, torch.float16, 4096, 1024, 0), (32, 64, torch.float16, 4096, 1024, 1), (64, 128, torch.bfloat16, 4096, 2048, 0),
         (64, 256, torch.float16, 4096, 1024, 1), (32, 128, torch.bfloat16, 8192, 1024, 0), (64, 64, torch.float16, 8192, 512, 0),
         (32, 256, torch.bfloat16, 2048, 1024, 0), (64, 64, torch.float16, 2048, 2048, 0), (32, 64, torch.bfloat16, 4096, 11008 // 128 * 128, 1),
+        (32, 64, torch.float16, 3584, 2048, 0), (64, 128, torch.bfloat16, 3584, 1024, 0), (32, 256, torch.float16, 3584, 512, 0),     # K = 7 pieces (Gemma-2-9B)
     ]
     ran = {1: 0, 2: 0, 4: 0}
     for (tile_p, g, dtype, K, N, rank) in cases:
@@ -356,14 +357,30 @@ def test_lean_decode_kernel(env):
         # the automatic plan of the same id is this kernel for one row while the layer is in the one-shot regime
         plan1 = dev.get_plan(1, N, K, bits, g, tid, env.num_sms, dtype, ovr)
         auto = dev.get_plan(1, N, K, bits, g, tid, env.num_sms, dtype)
-        if N * K <= (48 << 20) and env.num_sms <= 2 * plan1["grid"] <= 6 * env.num_sms and K != 8192:
+        if N * K <= (48 << 20) and env.num_sms <= 2 * plan1["grid"] <= (6 if K != 3584 else 2) * env.num_sms and K != 8192:
             assert auto["one_shot"] == 4, auto
         auto4 = dev.get_plan(4, N, K, bits, g, tid, env.num_sms, dtype)
         if N * K <= (16 << 20) and env.num_sms <= 2 * plan1["grid"] <= 2 * env.num_sms and K != 8192:      # one round of workgroups
             assert auto4["family"] == 0 and auto4["one_shot"] == 4 and auto4["m_block"] == 4, auto4
     assert min(ran.values()) > 0, ran
-    # not taken: five rows, 2 / 3 bits, 32-wide groups, K that is not 2048 / 4096 / 8192
-    for (M, K, bits, g) in ((5, 4096, 4, 64), (1, 4096, 2, 64), (1, 4096, 3, 64), (1, 4096, 4, 32), (1, 3584, 4, 64), (1, 14336, 4, 64)):
+    # flute.qgemm_hadamard (qgemm.cpp:201-244) never takes this kernel: the fused rotation stays with the round-4 one-shot kernel
+    # (measured, qgemm_fast.h) - the Hadamard call still fuses its rotation and its result is that of hadamard_transform
+    # followed by flute.qgemm, up to the order of the k sum
+    lib = env.fa._lib.get()
+    for (tile_p, g, dtype, K, N) in ((32, 64, torch.float16, 3584, 4096), (64, 128, torch.bfloat16, 4096, 3584 // 256 * 256)):
+        W, Q, S, table, table2 = make_case(env, 4, tile_p, g, dtype, K, N, seed=K % 71 + N % 17)
+        tid = template_ids_for(env.fa, 4, tile_p)[0]
+        Qd, Sd, td, t2d = Q.to(d), S.to(d), table.to(d), table2.to(d)
+        assert dev.get_plan(1, N, K, 4, g, tid, env.num_sms, dtype)["one_shot"] == 4
+        for h in (512, 2):
+            X = (torch.randn(1, K) / 10).to(dtype).to(d)
+            assert lib.flute_qgemm_hadamard_fused(0 if dtype == torch.float16 else 1, 4, g, h, 1, N, K, tid, env.num_sms, env.ws.numel()) == 1
+            auto = env.fa.qgemm_hadamard(X, Qd, Sd, td, t2d, env.ws, 4, g, h, tid, env.num_sms)
+            two = env.fa.qgemm(env.fa.hadamard_transform(X, h), Qd, Sd, td, t2d, env.ws, 4, g, tid, env.num_sms)
+            tol = 2e-3 if dtype == torch.float16 else 4e-3
+            assert rel_err(auto, two) < tol, (dtype, K, N, h)               # different kernels: the same products, summed in another order
+    # not taken: five rows, 2 / 3 bits, 32-wide groups, K that is not 2048 / 3584 / 4096 / 8192
+    for (M, K, bits, g) in ((5, 4096, 4, 64), (1, 4096, 2, 64), (1, 4096, 3, 64), (1, 4096, 4, 32), (1, 3072, 4, 64), (1, 14336, 4, 64)):
         plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=0, one_shot=4) if M <= 4 else dev.Overrides(one_shot=4))
         assert plan["one_shot"] != 4 or plan["family"] != 0, (M, K, bits, g, plan)
 
