@@ -71,12 +71,23 @@ class Layer:
         P = bits * N // 16
         self.Q, self.S = [], []
         gdev = torch.Generator(device=device).manual_seed(seed)
-        for _ in range(copies):
+        # One allocation for all the copies of Q and one for S (a checkpoint's layers loaded into one arena), not `copies`
+        # separate tensors from the caching allocator's 20-MB blocks: FLUTE_BENCH_ARENA=0 gives the latter (A/B)
+        arena = os.environ.get("FLUTE_BENCH_ARENA", "1") != "0"
+        if arena:
+            q_all = torch.empty((copies, P, K), dtype=torch.int16, device=device)
+            s_all = torch.empty((copies, N, K // g), dtype=dtype, device=device)
+        for c in range(copies):
             # any bit pattern is a valid packed matrix (all codes reachable for b=2,4;
             # for b=3 too): uniform int16 == uniform codes
-            self.Q.append(torch.randint(-2 ** 15, 2 ** 15, (P, K), dtype=torch.int16,
-                                        device=device, generator=gdev))
-            self.S.append(torch.randn(N, K // g, device=device, generator=gdev).to(dtype))
+            q = torch.randint(-2 ** 15, 2 ** 15, (P, K), dtype=torch.int16, device=device, generator=gdev)
+            sc = torch.randn(N, K // g, device=device, generator=gdev).to(dtype)
+            if arena:
+                q_all[c].copy_(q)
+                s_all[c].copy_(sc)
+                q, sc = q_all[c], s_all[c]
+            self.Q.append(q)
+            self.S.append(sc)
         self.template_id = None
         self.qgemm = flute_amd.qgemm
         self.hadamard_size = hadamard_size      # > 0: flute.qgemm_hadamard (rotation fused into the decode kernel)
