@@ -46,6 +46,11 @@ constexpr int kFamilyFastM = 7;                 // lean MFMA decode kernel: 4 un
 // Workspace layout (every kernel): [0, kXwgFlagBytes) tile state words of the in-launch reductions (xwg.h; zero between
 // calls), fp32 slabs behind them.  A planner sees the room behind the state words only.
 size_t slab_room(size_t workspace_bytes) { return workspace_bytes > kXwgFlagBytes ? workspace_bytes - kXwgFlagBytes : 0; }
+// development A/B (tools/time_cases.py): FLUTE_AMD_B3_TWO_LAUNCH=1 keeps the 3-bit blocks' K slices on fp32 slabs + the reduce launch
+bool block3_two_launch() {
+    static const bool v = [] { const char* e = getenv("FLUTE_AMD_B3_TWO_LAUNCH"); return e && e[0] == '1'; }();
+    return v;
+}
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
@@ -663,6 +668,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     //   256-row 97 / 120, bf16 101 / 124;  128-row 62 / 74, bf16 70 / 78 (profiles/r04/splitk_lab_run7*.jsonl);
     //   per-wave MFMA kernel (family 2): 520 ... 730 TFLOP/s fp16, 400 ... 560 bf16 for M = 256 ... 4096.
     int blk_cfg = -1, blk_sk = 0;                     // blk_sk: grid K split the cost model chose with the block shape (3 bits)
+    size_t blk_slabs = 0;                             // bytes of fragment-order slabs when a 3-bit block plan combines its K slices in the launch
     double alt_us = -1.0;                             // modelled time of the best other MFMA kernel (set by the block cost model)
     const int blk_units = 256 / J;                    // units of a 256-column block (4-bit: 64, 2-bit: 32, 3-bit: 16)
     const bool b3_ok = bits != 3 || (size_t)3 * (N >> 4) * K * 2 < (size_t)0xfffffff0u;   // one descriptor over Q
@@ -722,7 +728,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                                        (size_t)sk * M * N * 4 > slab_room(workspace_bytes))) continue;
                         double us;
                         if (sk == 1) us = block_us(tiles, alone, busy);
-                        else us = 4.0 + ((wgs * 4 >= (long)num_sms * 3 ? busy : alone) - 4.0) * (double)(K / sk) / 4096.0 + 5.0 +
+                        else us = 4.0 + ((wgs * 4 >= (long)num_sms * 3 ? busy : alone) - 4.0) * (double)(K / sk) / 4096.0 +
+                                  (rows == 128 ? 2.0 : 5.0) +              // (128-row blocks: combined in the launch, round 5; else the reduce launch)
                                   0.25 * (double)sk * M * N * 4.0 / 1e6;
                         if (us < 0.95 * best) { best = us; blk_cfg = rows == 128 ? 5 : 12; blk_sk = sk; }
                     }
@@ -838,6 +845,15 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         p->splitk = splitk; p->k_per_split = kps;
         p->grid = (unsigned)((long)tiles_m * tiles_n * splitk);
         p->block = 512;
+        // 3-bit 128-row blocks x 2 / 4 K slices (round 5): the slices of a block meet inside the launch (xwg.h, E form; slabs in
+        // fragment order, whole blocks: tiles x 128 x 256 x 4 B per slice) - no reduce launch.  Measured against the reduce launch
+        // (bf16, us, profiles/r05/call24_w3_inlaunch_and_line_planes.log): M = 1024 x 4096^2 56.3 -> 53.0 (fp16 53.4 -> 50.1),
+        // M = 256 x 8192^2 56.0 -> 54.4, M = 512 x 8192^2 95.3 -> 92.7, M = 96 x 28672 x 8192 92.1 -> 89.0, M = 512 x 4096^2 a tie; NOT for
+        // the skinny blocks (64 rows x 4 slices 46.7 -> 47.8; 8 slices, L form - the last arriver reads seven partials - 30.5 -> 32.6)
+        if (bits == 3 && (splitk == 2 || splitk == 4) && bm == 128 && (long)tiles_m * tiles_n <= (long)kXwgMaxTiles && !block3_two_launch()) {
+            const size_t slabs = (size_t)splitk * tiles_m * tiles_n * bm * 1024;
+            if (slabs <= slab_room(workspace_bytes) && slabs < ((size_t)1 << 31)) { p->splitk_mode = 1; blk_slabs = slabs; }
+        }
         // pair table + three activation stages + per wave: two scale blocks and a sink
         // (3-bit 256-row blocks: + 18 KB, the second / third plane pieces of waves 6 and 7)
         p->lds_bytes = (size_t)((128 << (2 * bits)) + 3 * (bm / 16) * 2 * 1024 + 8 * 3 * 1024 + ((bits == 3 && bm == 256) ? 18 * 1024 : 0));
@@ -934,7 +950,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         p->lut_copies = 32;
     }
     if (rc) return rc;
-    p->workspace_needed = p->splitk > 1 ? (size_t)p->splitk * M * N * 4 + kXwgFlagBytes : 0;
+    p->workspace_needed = p->splitk > 1 ? (blk_slabs ? blk_slabs : (size_t)p->splitk * M * N * 4) + kXwgFlagBytes : 0;
     if (p->lds_bytes > (size_t)kMaxLds) return FLUTE_ERR_SHAPE;
     return FLUTE_OK;
 }
@@ -1313,6 +1329,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         // XCD x (block id % 8) owns a contiguous range of row blocks (their activations then stay in its L2
         // while the weights stream through), else of column blocks
         b.order = (b.tiles_m % 8 == 0) ? 1 : ((b.tiles_n % 8 == 0) ? 2 : 0);
+        b.state = (p.splitk > 1 && p.splitk_mode == 1) ? reinterpret_cast<uint32_t*>(workspace) : nullptr;
         BlockKernel fn = (num_bits == 2) ? block_kernel_b2(dtype, t.tile_p, p.m_block)
                          : (num_bits == 3) ? block_kernel_b3(dtype, t.tile_p, p.m_block) : block_kernel_b4(dtype, t.tile_p, p.m_block);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
@@ -1323,7 +1340,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
             (void)hipGetLastError();
             return FLUTE_ERR_LAUNCH;
         }
-        if (p.splitk > 1) return splitk_reduce_dispatch(dtype, b.partial, D, (size_t)M * N, p.splitk, st);
+        if (p.splitk > 1 && p.splitk_mode == 0) return splitk_reduce_dispatch(dtype, b.partial, D, (size_t)M * N, p.splitk, st);
         return FLUTE_OK;
     }
 

@@ -38,7 +38,8 @@ struct BlockArgs {
     void* D;                // [M,N] T
     const void* S;          // [N,G] T
     const uint32_t* QM2;    // [4^b] pair table
-    float* partial;         // [splitk][M][N] fp32 when splitk > 1
+    float* partial;         // splitk > 1: fp32 slabs - [splitk][M][N] for the reduce launch, or (state != nullptr) in fragment order (xwg.h)
+    uint32_t* state;        // in-launch combine (xwg.h, round 5: qgemm_block3.h): two zero words per output tile; nullptr = reduce launch
     int M, N, K, G, lg;
     int tiles_m, tiles_n;   // workgroup tiles
     int splitk, k_per_split;    // k_per_split: multiple of lcm(64, 8 * group_size)

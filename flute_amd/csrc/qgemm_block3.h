@@ -13,8 +13,8 @@
 // needs all three planes (5 VALU per lookup), one of which is field 14's.  Three instantiations of the body, chosen
 // by a wave-uniform branch; all execute the same barriers.
 // Everything else is qgemm_block2.h (round 4: activations as whole-line 8-row x 128-B pieces too: 3-bit M = 4096 on
-// 4096^2 130.0 -> 127.9 us, M = 1024 on 28672 x 8192 478 -> 466; the PLANE pieces are still 16 rows x 64 B - a whole-line
-// plane piece would need a cross-lane shuffle or a trip through LDS): RT = 8 (128-row blocks) or, round 3, RT = 16 (256-row blocks).  Wave 7's ring of
+// 4096^2 130.0 -> 127.9 us, M = 1024 on 28672 x 8192 478 -> 466; the PLANE pieces stay 16 rows x 64 B - whole-line
+// plane pieces were measured in round 5 and dropped, below): RT = 8 (128-row blocks) or, round 3, RT = 16 (256-row blocks).  Wave 7's ring of
 // three plane pieces per half step x three stages is 72 registers - with 16 row tiles of accumulators (128) and every
 // wave of a kernel getting the same allocation, too many - so at RT = 16 the SECOND and THIRD plane pieces of waves 6
 // and 7 go to wave-private LDS by LDS-DMA (18 KB) and are read back, one half step ahead, with the fragments (246
@@ -24,21 +24,12 @@
 // The per-wave MFMA kernel (qgemm_tile.h) ran these layers at 360-380 TFLOP/s (M = 4096).
 #pragma once
 #include "qgemm_block2.h"
+#include "xwg.h"
 
-// Development variant, NOT measured yet (round 4 ended without GPU time for it; default 0 = off; 1 = every wave, 2 = all but the
-// wave of fields 14 / 15): the bit-plane pieces as WHOLE
-// cache lines too.  Today a plane piece is 16 unit rows x 64 B (one half step): 16 half lines per request, up to six requests
-// per step in the wave that owns field 15 - 350 line touches per step and CU against 64 for the 4-bit blocks, which is where
-// the static instruction mix says the 3-bit block's extra ~0.2 us per step goes (VALU per step: 52 .. 92 against 70 for 4
-// bits).  With the macro set a plane is fetched as two requests per STEP of 8 unit rows x 128 B (request A: units 0 .. 7,
-// request B: units 8 .. 15; lane (r16, q4) fetches chunk 4 (r16 >> 3) + q4 of unit r16 % 8): the same number of requests and
-// registers, half the lines; the words of half step h are put together by one DPP row_ror:8 move per dword (the scheme of
-// qgemm_block2.h's half_words, with two source registers), the LDS planes of the 256-row blocks are read back from the
-// source lane's slot.  tests/test_splitk_layout.py models the lane mapping.
-#ifndef FLUTE_B3_LINE_PLANES
-#define FLUTE_B3_LINE_PLANES 0
-#endif
-
+// Measured and dropped (round 5, profiles/r05/call24_w3_inlaunch_and_line_planes.log): the bit-plane pieces as WHOLE cache lines
+// (two requests per step of 8 unit rows x 128 B, the words of a half step put together by one DPP row_ror:8 move per dword - the
+// development variant FLUTE_B3_LINE_PLANES written at the end of round 4): M = 4096 on 4096^2 129.0 / 128.6 us against 127.3,
+// M = 1024 on 28672 x 8192 473 against 467 - the extra VALU (16 .. 44 per step) cost what the halved line count saved.
 namespace flute_amd {
 
 template <typename T, int RT>
@@ -122,21 +113,12 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
     const uint32_t wv_p0 = (uint32_t)u * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_p1 = (uint32_t)((a.N >> 4) + (u >> 5) * 64 + (u & 31)) * row_bytes + (uint32_t)q4 * 16u;
     const uint32_t wv_dp = 32u * row_bytes;
-    constexpr bool LINEP = FLUTE_B3_LINE_PLANES != 0;
-    // whole-line plane requests: unit (r16 & 7) [+ 8 for request B], chunk 4 (r16 >> 3) + q4 of its 128-B step
-    const int u8a = unit0 + (r16 & 7), u8b = u8a + 8;
-    const uint32_t lp_chunk = (uint32_t)((r16 >> 3) * 4 + q4) * 16u;
-    const uint32_t wvA_p0 = (uint32_t)u8a * row_bytes + lp_chunk, wvB_p0 = (uint32_t)u8b * row_bytes + lp_chunk;
-    const uint32_t wvA_p1 = (uint32_t)((a.N >> 4) + (u8a >> 5) * 64 + (u8a & 31)) * row_bytes + lp_chunk;
-    const uint32_t wvB_p1 = (uint32_t)((a.N >> 4) + (u8b >> 5) * 64 + (u8b & 31)) * row_bytes + lp_chunk;
     const uint32_t sc_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + (uint32_t)wave * 3072u;
     const uint32_t sc_sink = sc_base + 2048u;
     // RT = 16 (256-row blocks): the SECOND and THIRD plane pieces of waves 6 / 7 go to wave-private LDS (LDS-DMA) instead of
     // the register ring - 16 row tiles of accumulators leave no registers for three planes x three stages x two half steps
     const uint32_t pl_base = (uint32_t)LUT_BYTES + NST * STAGE_BYTES + NW * 3072u + (wave == 7 ? 6u * 1024u : 0u);   // wave-uniform (M0 of the DMA)
-    // (whole-line planes: the 16 B of half step h were fetched by lane (r16 % 8 + 8 h, q4) of request r16 >> 3; + 128 h is immediate)
     const uint32_t pl_lane = pl_base + (uint32_t)lane * 16u;
-    const uint32_t pl_lane_lp = pl_base + (uint32_t)(q4 * 16 + (r16 & 7)) * 16u;
     const uint32_t x_lds0 = x_mine ? (uint32_t)LUT_BYTES + (uint32_t)p0 * 1024u : sc_sink;     // idle request: zeros into the sink
 
     {   // pair table: 64 entries, 32 copies each (128-B stride)
@@ -157,7 +139,6 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         // KIND 0: both fields in one plane (one piece per half step); 1: two planes; 2: fields 14 and 15 (three planes)
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool LAST = KIND == 2;
-        constexpr bool LP = LINEP && !(LAST && FLUTE_B3_LINE_PLANES == 2);   // (2: the wave of fields 14 / 15 keeps its half-step pieces: + 44 VALU per step there otherwise)
         constexpr int NPL = KIND + 1;                              // weight pieces per half step
         constexpr int BATCH = PH + 2 * NPL + 1;
         constexpr int RPR = (BATCH + RT - 1) / RT;                 // requests issued after every row tile of half step 0
@@ -168,9 +149,6 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         const int pl0 = f0 % 3, pl1 = f1 % 3;
         const uint32_t wv0 = (pl0 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl0 - 1) * wv_dp;
         const uint32_t wv1 = (pl1 == 0) ? wv_p0 : wv_p1 + (uint32_t)(pl1 - 1) * wv_dp;
-        // (whole-line planes) the same for the two requests of a step: [request][tile's plane]
-        const uint32_t wvl[2][2] = {{(pl0 == 0) ? wvA_p0 : wvA_p1 + (uint32_t)(pl0 - 1) * wv_dp, (pl1 == 0) ? wvA_p0 : wvA_p1 + (uint32_t)(pl1 - 1) * wv_dp},
-                                    {(pl0 == 0) ? wvB_p0 : wvB_p1 + (uint32_t)(pl0 - 1) * wv_dp, (pl1 == 0) ? wvB_p0 : wvB_p1 + (uint32_t)(pl1 - 1) * wv_dp}};
         // scale block: lane L < 32 fetches 8 groups of column (unit L % 16, field f_(L / 16)); lane-linear image
         const uint32_t s_voff = (lane < 32)
             ? (uint32_t)(((size_t)(unit_col0<BITS, TILEP>(unit0 + (lane & 15)) + ((lane >> 4) ? f1 : f0) * TILEP) * a.G) * 2) : 0x80000000u;
@@ -181,7 +159,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
         constexpr int NX = NPL - NREG;
         u32x4_t w[NST][2][NREG];
         u32x4_t pw[NX > 0 ? NX : 1];                               // the LDS planes of the NEXT half step
-        const uint32_t pl_lane_k = LP ? pl_lane_lp + (uint32_t)(r16 >> 3) * (uint32_t)((NX > 0 ? NX : 1) * 1024) : pl_lane;
+        const uint32_t pl_lane_k = pl_lane;
         auto issue_one = [&](auto slot_tag, auto i_tag, int ustep) {
             constexpr int slot = decltype(slot_tag)::value;
             constexpr int i = decltype(i_tag)::value;
@@ -190,14 +168,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 dma16_buf(x_vo[i], x_srd, k0 * 2u,
                           x_lds0 + (x_mine ? (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES : 0u));
             } else if constexpr (i < PH + 2 * NPL) {
-                constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;        // (whole-line planes: h = request A / B of the step)
+                constexpr int h = (i - PH) / NPL, c = (i - PH) % NPL;
                 uint32_t vo;
-                if constexpr (LP) {
-                    if constexpr (LAST) vo = (c == 0) ? (h ? wvB_p0 : wvA_p0) : (h ? wvB_p1 : wvA_p1) + (uint32_t)(c - 1) * wv_dp;
-                    else vo = wvl[h][c == 0 ? 0 : 1];
-                } else if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
+                if constexpr (LAST) vo = (c == 0) ? wv_p0 : wv_p1 + (uint32_t)(c - 1) * wv_dp;     // planes 0, 1, 2
                 else vo = (c == 0) ? wv0 : wv1;
-                const uint32_t so = k0 * 2u + (LP ? 0u : (uint32_t)h * 64u);
+                const uint32_t so = k0 * 2u + (uint32_t)h * 64u;
                 if constexpr (XLDS && c >= 1)
                     dma16_buf(vo, w_srd, so, pl_base + (uint32_t)(((slot * 2 + h) * NX + (c - 1)) * 1024));
                 else
@@ -255,17 +230,8 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             constexpr int n = decltype(n_tag)::value;              // tile n / 4, word n % 4
             constexpr int ww = n & 3;
             constexpr int S_ = decltype(slot_tag)::value, H_ = decltype(h_tag)::value;
-            // word ww of register plane c for this lane's (unit, half step): the ring register itself, or (whole-line planes) put
-            // together from the two requests of the step - lanes r16 < 8 hold their unit in request A, lanes >= 8 in request B, the
-            // half step a lane lacks sits 8 lanes away in the same row (DPP row_ror:8, as qgemm_block2.h's half_words)
-            auto ring_word = [&](auto c_tag) -> uint32_t {
-                constexpr int c = decltype(c_tag)::value;
-                if constexpr (!LP) return w[S_][H_][c][ww];
-                else if constexpr (H_ == 0)
-                    return (uint32_t)__builtin_amdgcn_update_dpp((int)w[S_][0][c][ww], (int)w[S_][1][c][ww], 0x128 /* row_ror:8 */, 0xf, 0xc, false);
-                else
-                    return (uint32_t)__builtin_amdgcn_update_dpp((int)w[S_][1][c][ww], (int)w[S_][0][c][ww], 0x128 /* row_ror:8 */, 0xf, 0x3, false);
-            };
+            // word ww of register plane c for this lane's (unit, half step)
+            auto ring_word = [&](auto c_tag) -> uint32_t { return w[S_][H_][decltype(c_tag)::value][ww]; };
             const uint32_t q0w = ring_word(std::integral_constant<int, 0>{});
             const uint32_t q1w = XLDS ? pw[0][ww] : ring_word(std::integral_constant<int, (NREG > 1 ? 1 : 0)>{});
             const uint32_t q2w = XLDS ? pw[NX > 1 ? 1 : 0][ww] : ring_word(std::integral_constant<int, (NREG > 2 ? 2 : 0)>{});
@@ -287,8 +253,7 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                         u32x4_t& dst = pw[C];
                         const uint32_t addr = pl_lane_k;
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr),
-                                     "n"(LP ? (decltype(slot_tag)::value * 2 * NX + C) * 1024 + decltype(h_tag)::value * 128
-                                               : ((decltype(slot_tag)::value * 2 + decltype(h_tag)::value) * NX + C) * 1024) : "memory");
+                                     "n"(((decltype(slot_tag)::value * 2 + decltype(h_tag)::value) * NX + C) * 1024) : "memory");
                     }()), ...);
                 }(std::make_integer_sequence<int, NX>{});
             }
@@ -421,6 +386,26 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
 
         // ---- epilogue: accumulator register i of lane (r16, q4) = unit 4 q4 + i of the workgroup, i.e. four
         // consecutive columns of field f_t; the lane's output row is r16 ----
+        if constexpr (RT == 8) {
+            // 128-row blocks x 2 / 4 K slices combined INSIDE the launch (round 5, xwg.h, E form): the reference's Stream-K fix-up
+            // for any bit width (tile_scheduler_utils.hpp:58-211, :460-481).  Until round 4: [M][N] fp32 slabs and a reduce launch
+            // - kept (a.state == nullptr) for the 256-row blocks and for the skinny blocks, whose 4 - 8 slices of 16 .. 64 rows
+            // the reduce pass sums faster than their last arrivers would (measured, api.hip).
+            if (a.splitk > 1 && a.state != nullptr) {
+                const uint32_t col0 = (uint32_t)unit_col0<BITS, TILEP>(unit0 + 4 * q4);
+                auto store_d = [&](int i, int t, const f32x4_t o4) {
+                    const int orow = m0 + i * 16 + r16;
+                    if (orow < a.M) {
+                        uint2 o;
+                        o.x = (uint32_t)NT::from_float(o4[0]) | ((uint32_t)NT::from_float(o4[1]) << 16);
+                        o.y = (uint32_t)NT::from_float(o4[2]) | ((uint32_t)NT::from_float(o4[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)orow * a.N + col0 + (uint32_t)((t ? f1 : f0) * TILEP)) = o;
+                    }
+                };
+                xwg_seam<RT, NT2, NW>(acc, a.splitk, split, (uint32_t)bid, gridDim.x / (uint32_t)a.splitk, wave, lane, tid, a.partial, a.state, store_d);
+                return;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int orow = m0 + r * 16 + r16;

@@ -29,6 +29,8 @@
 // State per output tile, two words in the FIRST kXwgFlagBytes of the caller's workspace (the slabs start behind them):
 //   w0: arrivals;   w1: bit q = share q claimed by its owner, bit 16 + q = share q abandoned (published in full).
 #pragma once
+#include <utility>
+
 #include "common.h"
 
 namespace flute_amd {
@@ -123,6 +125,127 @@ __device__ __forceinline__ void xwg_reset(xwg_word* st, int tid) {
     if (tid == 0) {
         __hip_atomic_store(st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(st + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The whole seam of one output tile for a kernel whose waves hold the tile as NR x NC accumulator fragments (f32x4 per lane:
+// 1 KB per fragment and wave), NW waves per workgroup - round 5: the form qgemm_splitk.h's epilogue spells out, as a function,
+// for the 3-bit block kernel's K slices (qgemm_block3.h; until round 4 fp32 [M][N] slabs + a reduce LAUNCH).
+// Slabs in FRAGMENT order, [slice][tile][wave][i][t][lane] x 16 B: every store / load instruction of a wave moves one contiguous
+// KB and the same lane of the same wave of another slice finds its counterpart at the same place (the reference's
+// BlockStripedReduce does the same, tile_scheduler_utils.hpp:80-83).  E form when the slice count (2 or 4) divides NR - share q =
+// fragment rows q, q + nsl, ...; L form otherwise.  Sums in a fixed order (E: owner first, then the other slices ascending;
+// L: all slices ascending): the result does not depend on who arrives when.  store_d(i, t, sum) writes fragment (i, t) of D.
+// LDS dword 0 is the broadcast word: whatever the kernel kept there must be dead.  Every wave of the workgroup calls this.
+template <int NR, int NC, int NW, typename StoreD>
+__device__ __forceinline__ void xwg_seam(const f32x4_t (&own)[NR][NC], int nsl, int split, uint32_t tile, uint32_t ntiles,
+                                         int wave, int lane, int tid, float* partial, uint32_t* state, StoreD&& store_d) {
+    constexpr uint32_t TILE_SLAB = (uint32_t)NW * NR * NC * 1024u;
+    const __amdgpu_buffer_rsrc_t slab = xwg_rsrc(partial, (uint32_t)nsl * ntiles * TILE_SLAB);
+    const uint32_t slab_lane = tile * TILE_SLAB + (uint32_t)wave * (NR * NC * 1024u) + (uint32_t)lane * 16u;
+    auto slab_off = [&](int slice, int i, int t) {
+        return (uint32_t)slice * (ntiles * TILE_SLAB) + slab_lane + (uint32_t)(i * NC + t) * 1024u;
+    };
+    xwg_word* st = xwg_state(state + 2 * tile);
+    const uint32_t bcast = 0;
+
+    auto e_form = [&]<int NSH>(std::integral_constant<int, NSH>) {
+        constexpr int PER = NR / NSH;
+        const int me = split;
+        f32x4_t mine[PER][NC];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (i % NSH == me) {                                   // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NC; ++t) mine[i / NSH][t] = own[i][t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NC; ++t) xwg_store(own[i][t], slab, slab_off(me, i, t));
+            }
+        }
+        // share `sh`: first + the other slices' partials in ascending slice order -> D
+        auto combine = [&](int sh, const f32x4_t (&first)[PER][NC]) {
+            f32x4_t ld[PER][NC][NSH - 1];
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+#pragma unroll
+                    for (int o = 0; o < NSH - 1; ++o) {
+                        const int s2 = o + (o >= sh ? 1 : 0);      // the o-th slice other than the owner
+                        ld[jj][t][o] = xwg_load(slab, slab_off(s2, sh + jj * NSH, t));
+                    }
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    f32x4_t s = first[jj][t];
+#pragma unroll
+                    for (int o = 0; o < NSH - 1; ++o) s += ld[jj][t][o];
+                    store_d(sh + jj * NSH, t, s);
+                }
+        };
+        const uint32_t before = xwg_arrive(st, bcast, tid);
+        if (before == (uint32_t)(NSH - 1)) {
+            combine(me, mine);
+            const uint32_t ab = xwg_sweep(st, NSH, me, bcast, tid);
+            for (int q = 0; q < NSH; ++q) {
+                if (!((ab >> q) & 1u)) continue;                   // abandoned by its owner: every slice's partial of it is in place
+                f32x4_t first[PER][NC];
+#pragma unroll
+                for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) first[jj][t] = xwg_load(slab, slab_off(q, q + jj * NSH, t));
+                combine(q, first);
+            }
+            xwg_reset(st, tid);
+        } else if (xwg_wait_all(st, NSH, bcast, tid)) {
+            xwg_claim(st, me, tid);
+            combine(me, mine);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < PER; ++jj)
+#pragma unroll
+                for (int t = 0; t < NC; ++t) xwg_store(mine[jj][t], slab, slab_off(me, me + jj * NSH, t));
+            xwg_abandon(st, me, tid);
+        }
+    };
+
+    if (nsl == 4 && NR % 4 == 0) {
+        if constexpr (NR % 4 == 0) e_form(std::integral_constant<int, 4>{});
+    } else if (nsl == 2 && NR % 2 == 0) {
+        if constexpr (NR % 2 == 0) e_form(std::integral_constant<int, 2>{});
+    } else {
+        // L form: every slice publishes its whole partial; the last arriver sums ALL slices in ascending order (its own from
+        // the slab as well: one order whoever is last)
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int t = 0; t < NC; ++t) xwg_store(own[i][t], slab, slab_off(split, i, t));
+        const uint32_t before = xwg_arrive(st, bcast, tid);
+        if (before == (uint32_t)(nsl - 1)) {
+            f32x4_t s[NR][NC];
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int t = 0; t < NC; ++t) s[i][t] = xwg_load(slab, slab_off(0, i, t));
+            for (int s2 = 1; s2 < nsl; ++s2) {
+                f32x4_t ld[NR][NC];
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) ld[i][t] = xwg_load(slab, slab_off(s2, i, t));
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) s[i][t] += ld[i][t];
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int t = 0; t < NC; ++t) store_d(i, t, s[i][t]);
+            xwg_reset(st, tid);
+        }
     }
 }
 

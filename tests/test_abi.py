@@ -85,7 +85,11 @@ def test_plan_families_and_invariants():
             assert p.lds_bytes <= 160 * 1024
             assert p.waves * 64 == p.block and p.waves % p.kw == 0
             if p.splitk > 1:
-                assert p.workspace_needed == p.splitk * M * 4096 * 4 + (64 << 10) <= 64 << 20
+                rows = M
+                if p.family == 3 and bits == 3 and p.splitk_mode == 1:      # slabs of whole blocks, fragment order (xwg.h; round 5)
+                    assert p.m_block == 5 and p.splitk in (2, 4)
+                    rows = -(-M // 128) * 128
+                assert p.workspace_needed == p.splitk * rows * 4096 * 4 + (64 << 10) <= 64 << 20
                 assert p.k_per_split * p.splitk >= 4096 and p.k_per_split % 64 == 0
             else:
                 assert p.workspace_needed == 0 and p.k_per_split == 4096

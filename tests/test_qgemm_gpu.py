@@ -579,7 +579,10 @@ def test_block_prefill_kernel(env):
             for shp in (dict(family=3, m_tiles=8), dict(family=3, m_tiles=4),
                         dict(family=3, m_tiles=8, splitk=2), dict(family=3, m_tiles=4, splitk=2)):
                 ovr = dev.Overrides(**shp)
-                assert dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)["family"] == 3
+                plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
+                assert plan["family"] == 3
+                if "splitk" in shp:      # 3-bit blocks of up to 128 rows combine their K slices inside the launch (round 5), the others by a reduce launch
+                    assert plan["splitk_mode"] == (1 if bits == 3 and shp["m_tiles"] == 4 else 0), plan
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 err = rel_err(out, X.float() @ What)
                 assert err < tol_of(dtype), (tile_p, g, dtype, K, N, M, shp, err)
@@ -605,6 +608,7 @@ def test_block_prefill_kernel(env):
                 assert rel_err(out, X.float() @ What) < tol_of(dtype), (M, rt, sk)
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1, ref1), (M, rt, sk)
+    assert int(env.ws[:65536].view(torch.int32).abs().sum().item()) == 0        # the tile state words are zero again (xwg.h)
     p = dev.get_plan(64, 8192, 8192, 3, 64, 4, 256, torch.bfloat16)
     assert p["family"] == 3 and p["m_block"] == 12 and p["splitk"] > 1, p
     # the planner takes it by itself where the output has enough blocks
@@ -699,14 +703,17 @@ def test_splitk_seam_under_load(env):
     hand-off under uneven load, consumer caches warm, every word)."""
     import bench
     from flute_amd import dev
-    for (M, N, K, sk, fam, dtype, rt) in ((256, 4096, 4096, 4, 6, torch.float16, 8), (200, 2048, 4096, 8, 6, torch.bfloat16, 8),
-                                          (256, 2048, 8192, 2, 6, torch.float16, 8), (256, 4096, 4096, 2, 6, torch.float16, 4),
-                                          (200, 2048, 4096, 4, 6, torch.bfloat16, 4), (16, 4096, 4096, 4, 5, torch.float16, -1),
-                                          (9, 2048, 8192, 8, 5, torch.bfloat16, -1)):
-        lay = bench.Layer(M, N, K, 4, 64, dtype, env.dev, 3)
-        lay.template_id = template_ids_for(env.fa, 4, 32)[0]
-        lay.ovr = dev.Overrides(family=fam, splitk=sk, m_tiles=rt)
-        plan = dev.get_plan(M, N, K, 4, 64, lay.template_id, env.num_sms, dtype, lay.ovr)
+    # (bits 3, family 3: 2 / 4 K slices of qgemm_block3.h's 128-row blocks, round 5)
+    for (bits, M, N, K, sk, fam, dtype, rt, mb) in ((4, 256, 4096, 4096, 4, 6, torch.float16, 8, -1), (4, 200, 2048, 4096, 8, 6, torch.bfloat16, 8, -1),
+                                                    (4, 256, 2048, 8192, 2, 6, torch.float16, 8, -1), (4, 256, 4096, 4096, 2, 6, torch.float16, 4, -1),
+                                                    (4, 200, 2048, 4096, 4, 6, torch.bfloat16, 4, -1), (4, 16, 4096, 4096, 4, 5, torch.float16, -1, -1),
+                                                    (4, 9, 2048, 8192, 8, 5, torch.bfloat16, -1, -1),
+                                                    (3, 1024, 4096, 4096, 2, 3, torch.bfloat16, 4, -1), (3, 200, 2048, 4096, 4, 3, torch.float16, 4, -1),
+                                                    (3, 256, 8192, 8192, 4, 3, torch.bfloat16, 4, -1)):
+        lay = bench.Layer(M, N, K, bits, 64, dtype, env.dev, 3)
+        lay.template_id = template_ids_for(env.fa, bits, 32)[0]
+        lay.ovr = dev.Overrides(family=fam, splitk=sk, m_tiles=rt, m_block=mb)
+        plan = dev.get_plan(M, N, K, bits, 64, lay.template_id, env.num_sms, dtype, lay.ovr)
         assert plan["family"] == fam and plan["splitk"] == sk and plan["splitk_mode"] == 1, plan
         first = [lay.step(c).clone() for c in range(3)]
         torch.cuda.synchronize()
@@ -718,7 +725,7 @@ def test_splitk_seam_under_load(env):
         for _ in range(3):
             graph.replay()
             torch.cuda.synchronize()
-            assert all(torch.equal(o, first[i % 3]) for i, o in enumerate(outs)), (M, N, K, sk, fam)
+            assert all(torch.equal(o, first[i % 3]) for i, o in enumerate(outs)), (bits, M, N, K, sk, fam)
         assert _state_words_clean(env)
         del lay, outs, graph
         torch.cuda.empty_cache()

@@ -148,40 +148,3 @@ def test_xcd_pair_order_is_a_bijection():
     for t in range(2 * 86):
         per.setdefault(t % 8, []).append(remap(t, 2, 86))
     assert all(len({tn for _, tn in v}) <= len(v) // 2 + 1 for v in per.values())
-
-
-def test_block3_whole_line_plane_variant_lane_mapping():
-    """qgemm_block3.h, development variant FLUTE_B3_LINE_PLANES (not built by default, not measured yet): a bit plane is fetched
-    as two requests per 64-k step of 8 unit rows x 128 B; the 16 B a lane needs for half step h (unit = its MFMA row r16, bytes
-    64 h + 16 q4 of the unit's 128-B step row) come from its own register or, by DPP row_ror:8, from the lane 8 away in its
-    16-lane row; the LDS planes of the 256-row blocks are read back from the slot the fetching lane wrote.  Model of both."""
-    rows = np.arange(16 * 128, dtype=np.int64).reshape(16, 128)      # 16 units x the 128 bytes of one step; value = unit * 128 + byte
-    fetched = {}                                                       # (request, lane) -> first byte value of the 16 B it holds
-    for X in range(2):
-        for lane in range(64):
-            r16, q4 = lane & 15, lane >> 4
-            unit, chunk = (r16 & 7) + 8 * X, 4 * (r16 >> 3) + q4
-            fetched[(X, lane)] = rows[unit, chunk * 16]
-    for h in range(2):
-        for lane in range(64):
-            r16, q4 = lane & 15, lane >> 4
-            partner = (lane & ~15) | ((r16 + 8) & 15)                 # row_ror:8 inside the lane's row of 16
-            if h == 0:       # update_dpp(old = A, src = B, row_ror:8, bank_mask 0xc): lanes 8..15 of a row take B from the partner
-                got = fetched[(1, partner)] if r16 >= 8 else fetched[(0, lane)]
-            else:            # update_dpp(old = B, src = A, row_ror:8, bank_mask 0x3): lanes 0..7 take A from the partner
-                got = fetched[(0, partner)] if r16 < 8 else fetched[(1, lane)]
-            assert got == rows[r16, 64 * h + 16 * q4], (h, lane)
-    # LDS planes (RT = 16, waves 6 / 7): request X of (slot, plane c) is written lane-linearly at ((2 slot + X) NX + c) KB
-    for NX in (1, 2):
-        for slot in range(3):
-            for c in range(NX):
-                lds = {}
-                for X in range(2):
-                    for lane in range(64):
-                        lds[((slot * 2 + X) * NX + c) * 1024 + lane * 16] = fetched[(X, lane)]
-                for h in range(2):
-                    for lane in range(64):
-                        r16, q4 = lane & 15, lane >> 4
-                        base = (q4 * 16 + (r16 & 7)) * 16 + (r16 >> 3) * NX * 1024          # pl_lane_k - pl_base
-                        off = (slot * 2 * NX + c) * 1024 + h * 128                           # the immediate
-                        assert lds[base + off] == rows[r16, 64 * h + 16 * q4], (NX, slot, c, h, lane)
