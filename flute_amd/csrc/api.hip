@@ -55,6 +55,17 @@ bool block3_two_launch() {
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_pow2(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// 3-bit skinny blocks (64 rows x the K split the launcher will pick) on at least 80 % of the CUs?  Up to M = 48 the per-wave kernel
+// (three row tiles per wave) wins where they do not: 10240 x 8192 M = 48, 40 blocks x 4 slices = 160 workgroups, 44.5 us against 32.4;
+// with 224 - 256 workgroups the blocks win by 3 - 24 % (8192^2, 28672 x 8192, 8192 x 28672, 14336 x 4096, 4096 x 14336:
+// profiles/r05_planner_regret_between_*.json)
+bool skinny3_fills(int M, int col_blocks, int K, int lg, int num_sms) {
+    const long tiles = (long)ceil_div(M, 64) * col_blocks;
+    const int align_k = std::max(64, 8 << lg);
+    long sk = 1;
+    while (tiles * sk * 2 <= (long)num_sms && K / (sk * 2) >= std::max(256, align_k)) sk *= 2;
+    return tiles * sk * 5 >= (long)num_sms * 4;
+}
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // rows of a block-kernel configuration (flute_plan::m_block of family 3): 4 / 5 = 256 / 128 rows,
 // 8 + RT = the skinny 3-bit blocks of RT row tiles
@@ -681,7 +692,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (bits == 3 && ov.m_tiles != 8) blk_cfg = 5;   // 3-bit layers: 128-row blocks of qgemm_block3.h unless 256 rows are asked for ...
             if (bits == 3 && (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4))
                 blk_cfg = 8 + ov.m_block;                    // ... or its skinny blocks of m_block row tiles
-        } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)56 << 20)) {    // (14336 x 3584, 51 M weights: 29.5 against 26.4 us on the per-wave kernel)
+        } else if (bits == 3 && M > 32 && M <= 64 && (size_t)N * K >= ((size_t)56 << 20) &&
+                   (M > 48 || skinny3_fills(M, units / blk_units, K, lg, num_sms))) {    // (14336 x 3584, 51 M weights: 29.5 against 26.4 us on the per-wave kernel)
             // 3-bit skinny blocks (64 rows, grid K split): measured against the per-wave kernel at M = 64 - 8192^2 31.6 vs
             // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (fixed
             // costs of ~8 us per call: prologue, fp32 slabs, reduce launch)
@@ -703,7 +715,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // per-wave kernel: 520 (bf16 400) TFLOP/s at M = 256, + 55 per doubling of M, up to 730 (560)
             int dbl = 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;
-            const double wave_tf = (bits == 3) ? (bf ? 315.0 : 330.0)        // (round 4: 14336 x 3584 M = 256 runs at 305, modelled 370 kept it off the 128-row blocks: 86.4 against 70.3 us)
+            // (3 bits, round 4: 14336 x 3584 M = 256 runs at 305, modelled 370 kept it off the 128-row blocks: 86.4 against 70.3 us; round 5's
+            // regret sweep, fp16: 3584 x 8192 M = 256 293, 14336 x 3584 M = 128 276, 8192^2 M = 96 253 - fewer rows, fewer MFMAs per lookup)
+            const double wave_tf = (bits == 3) ? (bf ? 290.0 : 300.0) * (M >= 256 ? 1.0 : 0.6 + 0.4 * M / 256.0)
                                    : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl));
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
@@ -716,7 +730,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 // 64 rows: 66 / 72 - the lookups of a block's 256 columns dominate, the rows are nearly free), the slabs 0.25 us
                 // per MB + the reduce launch.  Measured (bf16, profiles/r04/w3_mid_m_forced_plans.jsonl; before -> after):
                 // M = 1024 x 4096^2 84.9 -> 56.4 us, M = 512 x 8192^2 160.5 -> 95.6, M = 512 x 4096^2 54.5 -> 45.4
-                double best = blk_cfg == 4 ? t256 : (blk_cfg == 5 ? t128 : wave_us);
+                const double base = blk_cfg == 4 ? t256 : (blk_cfg == 5 ? t128 : wave_us);
+                double best = 0.95 * base;                      // a K-split plan has to beat the unsplit best by 5 %; among themselves: the cheapest
                 const int align_k = std::max(64, 8 << lg);
                 for (int rows = 128; rows >= 64; rows >>= 1) {
                     const long tiles = (long)ceil_div(M, rows) * (units / blk_units);
@@ -724,17 +739,20 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                     const double busy = rows == 128 ? (bf ? 90.0 : 85.0) : (bf ? 72.0 : 70.0);
                     for (int sk = (rows == 128 ? 2 : 1); sk <= 4; sk *= 2) {
                         const long wgs = tiles * sk;
-                        if (sk > 1 && (wgs > (long)num_sms || K % (sk * align_k) || K / sk < 1024 ||
-                                       (size_t)sk * M * N * 4 > slab_room(workspace_bytes))) continue;
+                        // slices of kps k, the last one shorter where K is no multiple (K = 3584: 2048 + 1536, or 3 x 1024 + 512 - round 5:
+                        // 14336 x 3584 M = 128 47.6 -> 33.9 us, M = 256 61.7 -> 49.3; until then only equal slices were priced)
+                        const int kps = round_up(ceil_div(K, sk), align_k);
+                        if (sk > 1 && (wgs > (long)num_sms || ceil_div(K, kps) != sk || kps < 1024 ||
+                                       (size_t)sk * tiles * rows * 1024 > slab_room(workspace_bytes))) continue;
                         double us;
                         if (sk == 1) us = block_us(tiles, alone, busy);
-                        else us = 4.0 + ((wgs * 4 >= (long)num_sms * 3 ? busy : alone) - 4.0) * (double)(K / sk) / 4096.0 +
+                        else us = 4.0 + ((wgs * 4 >= (long)num_sms * 3 ? busy : alone) - 4.0) * (double)kps / 4096.0 +
                                   (rows == 128 ? 2.0 : 5.0) +              // (128-row blocks: combined in the launch, round 5; else the reduce launch)
                                   0.25 * (double)sk * M * N * 4.0 / 1e6;
-                        if (us < 0.95 * best) { best = us; blk_cfg = rows == 128 ? 5 : 12; blk_sk = sk; }
+                        if (us < best) { best = us; blk_cfg = rows == 128 ? 5 : 12; blk_sk = sk; }
                     }
                 }
-                alt_us = std::min(alt_us, best);
+                alt_us = std::min(alt_us, blk_sk > 0 ? best : base);
             }
         }
         if (blk_cfg >= 0) family = kFamilyBlock;
@@ -886,11 +904,23 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // profiles/r03/tile_lab_sw2_m16.jsonl, tile_lab_sw2_m32_m128.jsonl: 10240 x 8192 M = 16, 160 slabs: R = 1 22.2 us,
         // R = 2 26.8; M = 64: 36.7 / 49.9; 4096 x 11008 M = 64: 21.4 / 29.1; but 8192^2 M = 32, 128 slabs: R = 2 16.2, R = 1 19.3)
         auto fills = [&](long wgs) { return wgs * 20 >= 11L * num_sms * t.sms_multiple; };
-        while (combo_ok(R * 2, mt) && !fills((long)units * R / 16 * mtiles)) R *= 2;
+        // ... and not at all where the grid K split can fill the chip instead (round 5's regret sweep, the in-launch seam of xwg.h being
+        // cheap now): deep layers - K >= 10240: two slices, K >= 12288: four - stop sharing lanes as soon as that split fills.
+        // 4096 x 11008 (N x K) M = 4: four lanes per unit 16.6 us, two lanes x 2 slices 14.8 (2 bits: 14.2 -> 12.5), M = 16 16.9 -> 15.4;
+        // 3584 x 14336 M = 48: two lanes x 2 slices 26.4, no sharing x 4 slices 21.6 (profiles/r05_planner_regret_*.json)
+        const long deep_split = (bits != 3 && (bits != 4 || (template_id % 4) == 0) && ov.splitk < 0) ? (K >= 12288 ? 4 : (K >= 10240 ? 2 : 1)) : 1;
+        while (combo_ok(R * 2, mt) && !fills((long)units * R / 16 * mtiles) &&
+               !(deep_split > 1 && fills((long)units * R / 16 * mtiles * deep_split))) R *= 2;
         // QuantMapMode digit 1 (4-bit ids): no lane sharing above M = 16 - the chip is filled by the grid K split
         // instead (8192^2 M = 64: R = 1, MT = 4, split 2 26.2 us against R = 2, MT = 2 30.3; 4096^2 prefers R = 2:
         // the tuner decides)
         if (bits == 4 && (template_id % 4) == 1 && combo_ok(1, mt)) R = 1;       // (M <= 16: with two slabs per wave, below)
+        // QuantMapMode digit 3 above M = 16 (round 5): no lane sharing AND two slabs per wave, the chip filled by the grid K split - the
+        // plan round 4's regret sweep wanted on 8192 x 28672 and could not reach through an id (M = 64: 72.6 -> 55.3 us, M = 48 65.0 ->
+        // 52.8, M = 32 52.4 -> 45.2).  The automatic digit takes it by itself on layers that deep (K >= 16384: a slice keeps >= 4096 k) whose halved slab count x four slices fills the chip
+        const bool deep_sw2 = bits == 4 && M > 16 && combo_ok(1, mt) && (dtype == 0 || mt <= 2) && (units / 16) % 2 == 0 && ov.m_block <= 0 &&
+                              ((template_id % 4) == 3 || ((template_id % 4) == 0 && K >= 16384 && !fills((long)(units / 16) * mtiles) && fills((long)(units / 32) * mtiles * 4)));
+        if (deep_sw2) R = 1;
         if (ov.m_block > 0 && combo_ok(ov.m_block, mt)) R = ov.m_block;
         // SW = 2 slabs per wave (4-bit, no lane sharing, fp16 up to MT = 4 / bf16 up to MT = 2: the bf16 path
         // keeps a second accumulator set): every activation fragment then serves 8 column tiles and the
@@ -901,7 +931,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // ... as soon as the halved slab count still fills 55 % of the CUs (28672 x 8192 M = 16: 448 workgroups 43.4 us, 224
         // workgroups 37.1; M = 64: 73.4 -> 54.2; 4096 x 14336 M = 128: 38.2 -> 28.2) - or, at M <= 16, on the tuner's request (digit 1)
         if (sw_ok && (fills((long)(units / 32) * mtiles) || (mt == 1 && M <= 16 && (template_id % 4) == 1))) sw = 2;
-        if (sw_ok && bits == 4 && (template_id % 4) == 3) sw = 2;
+        if (sw_ok && bits == 4 && ((template_id % 4) == 3 || deep_sw2)) sw = 2;
         if (bits == 4 && (template_id % 4) == 2) sw = 1;
         if (sw_ok && ov.slabs == 2) sw = 2;
         if (ov.slabs == 1) sw = 1;

@@ -55,7 +55,8 @@ enum flute_status {
  *   stages        decode: which of the planner's ranked (waves, K split) shapes to launch (2 = best,
  *                 3/4/5 = the next ones); MFMA kernel: the neighbouring in-workgroup K splits
  *   lut_copies    the reference's QuantMapMode slot (1/32/16/8): MFMA kernel, 4-bit: automatic / no lane sharing
- *                 above M = 16 (the grid K split fills the chip instead) / one / two slabs per wave.  The kernels
+ *                 above M = 16 (the grid K split fills the chip instead) / one / two slabs per wave (above M = 16 the
+ *                 last one also means no lane sharing: two slabs per wave x the grid K split).  The kernels
  *                 always replicate the pair table 32x in LDS.
  * The decode kernel applies the group scale in fp32 to an 8-k partial sum: exact on
  * one-hot inputs, within 2^-11 relative per term of the reference's round_T(lut * s) otherwise. */
@@ -69,7 +70,7 @@ typedef struct flute_plan {
     int family;          /* 0 = decode (GEMV kernels, M<=4; 3 bits: M<=2; see one_shot), 2 = MFMA kernel with
                             LDS-DMA staged operands (every larger M), 3 = block-tiled prefill kernel
                             (enough 128 / 256 x 256 output blocks to fill the chip; 3-bit layers from M = 65 also 128- or
-                            64-row blocks x splitk K slices - m_block 5 / 12 - with fp32 slabs + the reduce pass), 5 = skinny MFMA kernel
+                            64-row blocks x splitk K slices - m_block 5 / 12; 128-row blocks x 2 / 4 slices meet inside the launch (splitk_mode 1), the others through fp32 slabs + the reduce pass), 5 = skinny MFMA kernel
                             (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
                             slabs fill 55..100 % of the CUs; weights and activations straight to registers),
                             6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, m_tiles x 16 rows (128 or 64) x 128 columns
