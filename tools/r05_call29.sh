@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, GPU call 29 (final library): the whole GPU suite, smoke(), the bench lines (driver's 20 steps and 2 000), rocprofv3 passes of the bench
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_final.log 2>&1; tail -3 gpurun_out/pytest_gpu_final.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_20.json 2> gpurun_out/bench_20.err
+python bench.py --steps 2000 --warmup 50 > gpurun_out/bench_2000.json 2> gpurun_out/bench_2000.err
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+for f in bench_20 bench_2000 bench_default; do python - $f <<'PY'
+import json, sys
+j = json.loads(open("gpurun_out/" + sys.argv[1] + ".json").read().strip().splitlines()[-1]); r = j["roofline"]
+print(sys.argv[1], j["value"], j["unit"], "us", r.get("kernel_us"), "events", r.get("kernel_us_hip_events"), "m256", j.get("m256", {}).get("us"))
+PY
+done
+timeout 600 bash tools/prof_bench.sh > gpurun_out/prof_bench.log 2>&1; tail -5 gpurun_out/prof_bench.log
