@@ -366,13 +366,12 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         using cur_t = std::integral_constant<int, h>;
         using nxt_t = std::integral_constant<int, nh>;
         wait_lds(cur_t{});
-        if constexpr (h == 0) {
-            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();   // (A) stage t-1 is free: batch t+2 follows, spread over the rows
-        } else {
-            // (B) batch t+1 has landed once at most batch t+2 is outstanding
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(BATCH) : "memory");
-            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
-        }
+        // (B) batch t+1 has landed once at most batch t+2 is outstanding
+        if constexpr (h == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(BATCH) : "memory");
+        // Round 5: everything of this half step that touches only the wave's own registers and its private scale image - the scale
+        // multiplies of the weights, the next half step's scale reads and word shuffle - is done BEFORE the workgroup meets: it overlaps
+        // the tail of the previous half step's MFMAs and the wait for the last wave, and after the barrier every wave starts with MFMAs
+        // (64-row tiles: M = 256 x 4096^2 19.45 -> 19.25 us, M = 64 x 8192^2 20.05 -> 19.74; 128-row tiles: equal - profiles/r05/call34_*.log).
         u32x4_t bf[NT2];
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
@@ -382,6 +381,9 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
         }
         scales(nxt_t{}, t + h, nh);
         const u32x4_t qw = half_words(w[nslot], nxt_t{});
+        asm volatile("" : "+v"(bf[0]), "+v"(bf[1]) : : "memory");     // (keeps hipcc from sinking the multiplies below the barrier)
+        // (A) [h = 0] stage t-1 is free: batch t+2 follows, spread over the rows; (B) [h = 1] stage t+1 is complete
+        if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
 #pragma unroll
