@@ -297,13 +297,11 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             constexpr int nslot = h ? (slot + 1) % NST : slot;
             constexpr int nh = h ^ 1;
             wait_lds();
-            if constexpr (h == 0) {
-                __builtin_amdgcn_s_barrier();                      // (A) stage t-1 is free: batch t+NST-1 follows, spread over the rows
-            } else {
-                // (B) batch t+1 has landed once at most batches t+2 .. t+NST-1 are outstanding
-                wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, (NST - 2) * BATCH>{});
-                __builtin_amdgcn_s_barrier();
-            }
+            // (B) batch t+1 has landed once at most batches t+2 .. t+NST-1 are outstanding
+            if constexpr (h == 1) wait_batch(std::integral_constant<int, nslot>{}, std::integral_constant<int, (NST - 2) * BATCH>{});
+            // (round 5, as qgemm_splitk.h) what touches only the wave's own registers, scale image and LDS planes runs BEFORE the workgroup meets:
+            // 128-row blocks x 2 K slices, M = 1024 on 4096^2 bf16: 53.4 -> 50.9 us; 256-row blocks: equal (same-box A/B, profiles/r05/call35_*.log;
+            // the 2- / 4-bit blocks of qgemm_block2.h measured 1 % SLOWER that way in fp16 and keep their order)
             u32x4_t bf[NT2];
 #pragma unroll
             for (int c = 0; c < NT2; ++c)
@@ -311,6 +309,9 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
                 for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], scn[c]);
             scales(t + h, nh);
             planes(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{});
+            asm volatile("" : "+v"(bf[0]), "+v"(bf[1]) : : "memory");     // (keeps hipcc from sinking the multiplies below the barrier)
+            // (A) [h = 0] stage t-1 is free: batch t+NST-1 follows, spread over the rows; (B) [h = 1] stage t+1 is complete
+            __builtin_amdgcn_s_barrier();
             auto row = [&](auto r_tag) {
                 constexpr int R = decltype(r_tag)::value;
                 if constexpr (R >= 8) {
