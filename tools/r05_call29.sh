@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 29 (final library): the whole GPU suite, smoke(), the bench lines (driver's 20 steps and 2 000), rocprofv3 passes of the bench
+# round 5, GPU calls 29 and 36 (final library): the whole GPU suite, smoke(), the bench lines (driver's 20 steps and 2 000), rocprofv3 passes of the bench
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -14,4 +14,3 @@ j = json.loads(open("gpurun_out/" + sys.argv[1] + ".json").read().strip().splitl
 print(sys.argv[1], j["value"], j["unit"], "us", r.get("kernel_us"), "events", r.get("kernel_us_hip_events"), "m256", j.get("m256", {}).get("us"))
 PY
 done
-timeout 600 bash tools/prof_bench.sh > gpurun_out/prof_bench.log 2>&1; tail -5 gpurun_out/prof_bench.log
