@@ -43,6 +43,10 @@ template <> struct Num<F16> {
         h2_t bb = {b.x, b.x};
         return __builtin_bit_cast(uint32_t, a * bb);           // v_pk_mul_f16 op_sel
     }
+    static __device__ __forceinline__ void mul_scale4(const uint32_t (&v)[4], uint32_t s, uint32_t (&out)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = mul_scale(v[i], s);
+    }
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a),
                                       __builtin_bit_cast(h2_t, b), c, false);
@@ -70,6 +74,34 @@ template <> struct Num<BF16> {
         float sf = __builtin_bit_cast(float, s << 16);
         b2_t r = {(__bf16)(lo * sf), (__bf16)(hi * sf)};        // v_cvt_pk_bf16_f32
         return __builtin_bit_cast(uint32_t, r);
+    }
+    // The four words of a column tile times one scale (the block kernels' multiply stage), round 5: the two fp32 products of a word come
+    // straight out of the packed word - v_dot2_f32_bf16 against (s, 0) and (0, s): lo * s + hi * 0 and lo * 0 + hi * s, exact (one
+    // term is zero; the pair tables hold finite values) - then one v_cvt_pk_bf16_f32: 3 VALU per word where unpack / multiply / convert
+    // takes 4 (gfx950 has no packed bf16 multiply).  ONE asm block: a DOT result read by another VALU instruction needs three wait
+    // states on gfx90a+ and hipcc's hazard recognizer does not look into asm statements (a per-word version with the conversion right
+    // behind its products computed wrong values in one kernel: caught by test_random_vs_oracle_all_M) - the eight products first, the
+    // conversions behind them in the same order, so that every conversion is >= 3 instructions behind its second product; the closing
+    // s_nop keeps a following MFMA off the last conversion's result.
+    static __device__ __forceinline__ void mul_scale4(const uint32_t (&v)[4], uint32_t s, uint32_t (&out)[4]) {
+        const uint32_t s_lo = s & 0xffffu, s_hi = s << 16;
+        float p0, p1, p2, p3, p4, p5, p6, p7;
+        asm("v_dot2_f32_bf16 %4, %12, %16, 0\n\t"
+            "v_dot2_f32_bf16 %5, %12, %17, 0\n\t"
+            "v_dot2_f32_bf16 %6, %13, %16, 0\n\t"
+            "v_dot2_f32_bf16 %7, %13, %17, 0\n\t"
+            "v_dot2_f32_bf16 %8, %14, %16, 0\n\t"
+            "v_dot2_f32_bf16 %9, %14, %17, 0\n\t"
+            "v_dot2_f32_bf16 %10, %15, %16, 0\n\t"
+            "v_dot2_f32_bf16 %11, %15, %17, 0\n\t"
+            "v_cvt_pk_bf16_f32 %0, %4, %5\n\t"
+            "v_cvt_pk_bf16_f32 %1, %6, %7\n\t"
+            "v_cvt_pk_bf16_f32 %2, %8, %9\n\t"
+            "v_cvt_pk_bf16_f32 %3, %10, %11\n\t"
+            "s_nop 1"
+            : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]),
+              "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s_lo), "v"(s_hi));
     }
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a),

@@ -304,9 +304,12 @@ __global__ __launch_bounds__(512) void qgemm_block3_kernel(const BlockArgs args)
             // the 2- / 4-bit blocks of qgemm_block2.h measured 1 % SLOWER that way in fp16 and keep their order)
             u32x4_t bf[NT2];
 #pragma unroll
-            for (int c = 0; c < NT2; ++c)
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[c * 4 + ww], scn[c]);
+            for (int c = 0; c < NT2; ++c) {
+                const uint32_t vin[4] = {v[c * 4], v[c * 4 + 1], v[c * 4 + 2], v[c * 4 + 3]};
+                uint32_t o[4];
+                NT::mul_scale4(vin, scn[c], o);
+                bf[c] = u32x4_t{o[0], o[1], o[2], o[3]};
+            }
             scales(t + h, nh);
             planes(std::integral_constant<int, nslot>{}, std::integral_constant<int, nh>{});
             asm volatile("" : "+v"(bf[0]), "+v"(bf[1]) : : "memory");     // (keeps hipcc from sinking the multiplies below the barrier)

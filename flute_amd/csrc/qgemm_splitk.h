@@ -376,8 +376,10 @@ __global__ __launch_bounds__(512 + 64 * LDW) void qgemm_splitk_kernel(const Spli
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
             const uint32_t sj = scn[h][c];
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) bf[c][ww] = NT::mul_scale(v[h][c * 4 + ww], sj);
+            const uint32_t vin[4] = {v[h][c * 4], v[h][c * 4 + 1], v[h][c * 4 + 2], v[h][c * 4 + 3]};
+            uint32_t o[4];
+            NT::mul_scale4(vin, sj, o);
+            bf[c] = u32x4_t{o[0], o[1], o[2], o[3]};
         }
         scales(nxt_t{}, t + h, nh);
         const u32x4_t qw = half_words(w[nslot], nxt_t{});
