@@ -64,3 +64,18 @@ def test_audit_rules_on_synthetic_streams(tmp_path):
     # ... but only as THAT source: the same register named as destination or as another source is still touched
     assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[4:5], v[3:4], v[36:37] op_sel_hi:[0,1]\n" + wait0)) == 1
     assert len(_audit_text(tmp_path, load + "\tv_pk_mul_f32 v[36:37], v[3:4], v[4:5] op_sel_hi:[0,1]\n" + wait0)) == 1
+    # round 5: a v_dot* result read by ANOTHER VALU instruction (or by a v_dot* as its A / B operand) less than three wait states later
+    # (gfx90a+; hipcc keeps it for its own instructions, not inside asm statements) is flagged ...
+    dot = "\tv_dot2_f32_bf16 v10, v2, v3, 0\n"
+    assert len(_audit_text(tmp_path, dot + "\tv_cvt_pk_bf16_f32 v20, v10, v11\n")) == 1
+    assert len(_audit_text(tmp_path, dot + "\tv_mov_b32_e32 v30, v1\n\tv_mov_b32_e32 v31, v1\n\tv_cvt_pk_bf16_f32 v20, v10, v11\n")) == 1
+    assert len(_audit_text(tmp_path, dot + "\tv_dot2_f32_bf16 v12, v10, v3, 0\n")) == 1
+    # ... three instructions (or an s_nop 2) later it is not, nor as the NEXT dot's accumulator
+    assert _audit_text(tmp_path, dot + "\tv_mov_b32_e32 v30, v1\n" * 3 + "\tv_cvt_pk_bf16_f32 v20, v10, v11\n") == []
+    assert _audit_text(tmp_path, dot + "\ts_nop 2\n\tv_cvt_pk_bf16_f32 v20, v10, v11\n") == []
+    assert _audit_text(tmp_path, dot + "\tv_dot2_f32_bf16 v10, v4, v5, v10\n") == []
+    # the multiply stage of common.h's Num<BF16>::mul_scale4: eight products, then the conversions in the same order
+    blk = "".join(f"\tv_dot2_f32_bf16 v{10 + i}, v{2 + i // 2}, v{6 + i % 2}, 0\n" for i in range(8)) + \
+          "".join(f"\tv_cvt_pk_bf16_f32 v{20 + i}, v{10 + 2 * i}, v{11 + 2 * i}\n" for i in range(4))
+    assert _audit_text(tmp_path, blk) == []
+

@@ -13,7 +13,13 @@ load into it is still outstanding.
     python tools/audit_asm_loads.py [file.s ...]      # no arguments: compiles the instantiation units to .s
 
 Exit status 1 if anything is flagged.  A linear replay cannot follow branches, so loop-carried state is
-approximate: it is a lint for the straight-line mistakes, not a proof."""
+approximate: it is a lint for the straight-line mistakes, not a proof.
+
+Round 5 added a second rule, on every instruction of the unit: a VGPR written by a v_dot* instruction may be read by another VALU
+instruction (or by a v_dot* as its A / B operand) only three wait states later (gfx90a+).  hipcc's hazard recognizer keeps that for
+the instructions it schedules but does not look into asm statements: a per-word bf16 scale multiply written as v_dot2_f32_bf16 asm
+statements with the conversion right behind them computed wrong values (tests/test_qgemm_gpu.py caught it; common.h mul_scale4 is the
+form that keeps the distance by construction)."""
 import os
 import re
 import subprocess
@@ -117,6 +123,33 @@ def _dead_readfirstlane(lines, i, text):
     return False
 
 
+DOT = re.compile(r"^(v_dot\w+)\s+(v\d+|v\[\d+:\d+\])\s*,")
+
+
+def _dot_hazard(recent, text, used_srcs):
+    """gfx90a+ (LLVM GCNHazardRecognizer: DotWriteDifferentVALURead = DotWriteSameDotReadSrcAB = 3): the VGPR a v_dot* instruction
+    wrote may be read by another VALU instruction - or by a v_dot* as its A / B operand - only three wait states later (as the C
+    operand of the next v_dot* at once).  hipcc keeps that for the instructions it schedules, NOT inside asm statements (round 5: a
+    v_dot2_f32_bf16 asm statement whose result reached v_cvt_pk_bf16_f32 one instruction later computed wrong values).  `recent`:
+    [(wait states since, dst regs)] of the last dots.  Returns the registers read too early."""
+    if not text.startswith("v_"):
+        return set()
+    bad = set()
+    m = DOT.match(text)
+    for age, dst in recent:
+        if age >= 3:
+            continue
+        if m:                                              # a dot reading an earlier dot's result: allowed as src C (the last source) only
+            ops = [o.strip() for o in text[m.end():].split(",")]
+            ab = set()
+            for o in ops[:2]:
+                ab |= regs_of(o)
+            bad |= ab & dst
+        else:
+            bad |= used_srcs & dst
+    return bad
+
+
 def audit(path):
     findings = []
     all_lines = open(path).read().split("\n")
@@ -124,6 +157,7 @@ def audit(path):
     in_asm = False
     vm_fifo = []          # hidden VMEM loads in flight: (line number, set of VGPRs)
     ds_set = []           # hidden LDS loads in flight
+    dots = []             # [wait states since issue, dst regs] of recent v_dot* instructions
     for ln, raw in enumerate(open(path), 1):
         line = raw.split(";")[0].rstrip() if not raw.lstrip().startswith(";;#") else raw.strip()
         if raw.lstrip().startswith(";;#ASMSTART"):
@@ -156,6 +190,22 @@ def audit(path):
             n = int(ml.group(1))
             if n < len(ds_set):
                 ds_set = ds_set[len(ds_set) - n:] if n > 0 else []
+        # ---- DOT result read too early (any instruction, asm statement or not) ----
+        if text.startswith("s_nop"):
+            mm = re.match(r"s_nop\s+(\d+)", text)
+            for d in dots:
+                d[0] += int(mm.group(1)) + 1 if mm else 1
+        elif not text.startswith((".", ";")):
+            md = DOT.match(text)
+            srcs = regs_of(text.split(",", 1)[1]) if "," in text else set()
+            early = _dot_hazard([(a, r) for a, r in dots], text, srcs)
+            if early:
+                findings.append((kernel, ln, text + "   [DOT result read within 3 wait states]", sorted(early)))
+            for d in dots:
+                d[0] += 1
+            if md:
+                dots.append([0, regs_of(md.group(2))])
+            dots = [d for d in dots if d[0] < 3]
         if text.startswith("s_waitcnt"):
             continue
         used = regs_of(text)
