@@ -135,3 +135,46 @@ def test_l_form_last_arriver_sees_every_partial(nsl):
     for seed in range(1000):
         tile = run(nsl, seed, "L")
         assert not tile.errors and len(tile.combined) == 1 and tile.w0 == 0, (seed, tile.errors, tile.combined)
+
+
+@pytest.mark.parametrize("nr,nc,nw", [(8, 2, 8), (4, 2, 8), (2, 2, 8), (1, 2, 8), (4, 2, 12)])
+def test_xwg_seam_fragment_shares_and_slab_addresses(nr, nc, nw):
+    """csrc/xwg.h `xwg_seam<NR, NC, NW>` (round 5: the split-K kernel's epilogue as a function, used by qgemm_block3.h): which fragment rows
+    a slice keeps / publishes, and where they live in the slabs.  E form (2 or 4 slices dividing NR): share q = fragment rows q, q + nsl,
+    ...; slice s keeps share s and publishes the others at [slice][tile][wave][row][column tile][lane] x 16 B.  Checked: every fragment
+    of every wave is owned by exactly one slice, the owner reads exactly the other slices' copies of ITS fragments from the addresses they
+    were written to, no two (slice, tile, wave, fragment, lane) share bytes, and everything stays inside nsl x ntiles x TILE_SLAB."""
+    tile_slab = nw * nr * nc * 1024
+    ntiles = 5
+
+    def off(slc, tile, wave, i, t, lane):
+        return slc * (ntiles * tile_slab) + tile * tile_slab + wave * (nr * nc * 1024) + (i * nc + t) * 1024 + lane * 16
+
+    for nsl in (2, 4, 3, 8):
+        e_form = nsl in (2, 4) and nr % nsl == 0
+        tile = 3
+        written = {}
+        for s in range(nsl):
+            for wave in range(nw):
+                for i in range(nr):
+                    if e_form and i % nsl == s:
+                        continue                                   # the owner's share stays in registers
+                    for t in range(nc):
+                        for lane in (0, 17, 63):
+                            o = off(s, tile, wave, i, t, lane)
+                            assert 0 <= o and o + 16 <= nsl * ntiles * tile_slab
+                            assert o not in written
+                            written[o] = (s, wave, i, t, lane)
+        owners = {}
+        for s in range(nsl):                                       # what each slice combines (E: its share; L: the last arriver, everything)
+            for wave in range(nw):
+                rows = [i for i in range(nr) if i % nsl == s] if e_form else (list(range(nr)) if s == nsl - 1 else [])
+                for i in rows:
+                    owners.setdefault((wave, i), []).append(s)
+                    for t in range(nc):
+                        for other in range(nsl):
+                            if other == s and e_form:
+                                continue
+                            assert written[off(other, tile, wave, i, t, 17)] == (other, wave, i, t, 17)
+        assert all(len(v) == 1 for v in owners.values()) and len(owners) == nw * nr
+
