@@ -812,7 +812,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // (M = 2) and the skinny MFMA kernel (M = 3, 4) win: 8192 x 4096 5.79 against 7.12, 8.69 against 8.98).  Never for a call that
         // fuses the Hadamard rotation.  K = 8192 (shape (8, 2, 8)), round 5's last call series: one row a tie with the one-shot kernel
         // (3584 x 8192: 5.33 / 5.40 us, 4096 x 8192: 5.57 / 5.51), TWO rows on layers that give >= 80 % of the CUs a workgroup 6.11 against
-        // 6.78 and 6.33 against 6.82 - taken; narrower layers (2048, 1024 columns: 128 / 64 workgroups) lose 13 - 17 % and are not
+        // 6.78 and 6.33 against 6.82 - taken; narrower layers (2048, 1024 columns: 128 / 64 workgroups) lose 13 - 17 % and are not.
+        // K = 2048, two rows: up to two rounds (6144 x 2048 4.34 -> 3.79 us, 8192 x 2048 4.38 -> 4.01; four rows lose there: 5.14 / 5.76)
         if ((want == 4 || (want < 0 && bits == 4 && (template_id % 4) == 0 && t.stages <= 3 && t.sms_multiple == 1 && ov.waves < 0)) &&
             !ov.had8 && ov.kw < 0) {
             flute_plan q;
@@ -820,7 +821,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             if (plan_fast(bits, lg, M, N, K, num_sms, std::max(0, t.stages - 2), want == 4 ? ov.waves : -1, &q, oa) == FLUTE_OK &&
                 (want == 4 || ((K != 8192 || (M == 2 && (long)q.grid * 5 >= (long)num_sms * 4)) &&
                                (size_t)N * K <= ((size_t)48 << 20) && (long)q.grid * 2 >= (long)num_sms &&
-                               (long)q.grid <= (M == 1 ? 3L : 1L) * num_sms))) {
+                               (long)q.grid <= (M == 1 ? 3L : (M == 2 && K == 2048 ? 2L : 1L)) * num_sms))) {
                 *p = q;
                 taken = true;
             }
