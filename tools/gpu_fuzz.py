@@ -57,11 +57,11 @@ for case in range(ncases):
     if os.environ.get("FUZZ_DECODE") == "2":                    # one row, K in whole 1024-k steps (persistent one-shot kernel)
         M = 1
         K = max(1024, K // 1024 * 1024)
-    if os.environ.get("FUZZ_DECODE") == "3":                    # round 5: the lean kernels' shapes (4 bits, K = 2048 / 3584 / 4096, M <= 16; automatic ids often)
+    if os.environ.get("FUZZ_DECODE") == "3":                    # round 5: the lean kernels' shapes (4 bits, K = 2048 / 3584 / 4096 / 8192, M <= 16; automatic ids often)
         if bits != 4:
             continue
         M = rng.choice([1, 1, 2, 3, 4, 5, 8, 9, 16])
-        K = rng.choice([2048, 3584, 4096, 4096])
+        K = rng.choice([2048, 3584, 4096, 4096, 8192])
         g = rng.choice([64, 64, 128, 256])
         if rng.random() < 0.6:
             tid = rng.choice([t for t in tids if t % 4 == 0 and t < 32] or tids)
