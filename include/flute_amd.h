@@ -98,7 +98,7 @@ typedef struct flute_plan {
                             wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
                             (qgemm_persist.h: table / activations staged once, every wave walks `visits` units of
                             `k_chunks` segments of ring_depth pieces, the next segment requested ahead), 4 = lean decode
-                            kernel (qgemm_fast.h, round 5: 4 bits, M <= 4, K = 512 * ring_depth * kw in {2048, 4096, 8192}
+                            kernel (qgemm_fast.h, round 5: 4 bits, M <= 4, K = 512 * ring_depth * kw in {2048, 3584, 4096, 8192}
                             a compile-time constant, m_block rows per pass) */
     int splitk_mode;     /* splitk > 1: 0 = fp32 slabs in the workspace + a second (reduce) launch, 1 = combined inside the
                             launch (csrc/xwg.h: write-through slabs + one arrival word per output tile) */
@@ -122,7 +122,7 @@ typedef struct flute_plan {
  *                   one_shot = 1 a given depth selects the ring kernel
  *   one_shot        decode: 1 one-shot kernel, 0 persistent ring kernel, 3 persistent one-shot kernel (M <= 2) - the code
  *                   flute_plan.one_shot reports for it; 2, ABI v4's value for the same request, is still accepted; 4 lean decode
- *                   kernel (4 bits, M <= 4, K in {2048, 4096, 8192}; `waves` 4 / 8 picks its shape; what it cannot take falls back) */
+ *                   kernel (4 bits, M <= 4, K in {2048, 3584, 4096, 8192}; `waves` 4 / 8 picks its shape; what it cannot take falls back) */
 typedef struct flute_overrides {
     int family, m_block, waves, kw, splitk, m_tiles, slabs_per_wave, ring_depth, one_shot;
 } flute_overrides;
