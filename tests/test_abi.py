@@ -401,3 +401,42 @@ def test_qgemm_hadamard_entry_host_logic():
     assert lib.flute_qgemm_hadamard(*(head + tail)) == -9           # null tensors, fused plan: refused before launch
     head[4] = 9
     assert lib.flute_qgemm_hadamard(*(head + tail)) == -9           # unfused plan without scratch
+
+
+def test_round5_planner_rules():
+    """The plans the round-5 regret sweeps asked for (profiles/r05_planner_regret_*.json), as host logic: no GPU."""
+    # two slabs per wave x the grid K split on a deep layer: QuantMapMode digit 3 above M = 16, and the automatic digit for K >= 16384
+    for tid in (0, 3, 16):
+        rc, p = plan(64, 8192, 28672, tid=tid)
+        assert rc == 0 and (p.family, p.m_block, p.slabs_per_wave, p.splitk, p.grid) == (2, 1, 2, 4, 256), (tid, p.as_dict())
+    rc, p = plan(64, 8192, 28672, tid=1)                          # digit 1 keeps its meaning: no lane sharing, one slab per wave
+    assert rc == 0 and (p.family, p.m_block, p.slabs_per_wave) == (2, 1, 1)
+    rc, p = plan(16, 8192, 28672, tid=3)                          # digit 3 at M <= 16: unchanged (the skinny kernel / two slabs per wave)
+    assert rc == 0 and p.family in (2, 5)
+    # a grid K split instead of more lane sharing on deep layers (K >= 10240: two slices, K >= 12288: four)
+    rc, p = plan(4, 4096, 11008)
+    assert rc == 0 and (p.family, p.m_block, p.splitk, p.grid) == (2, 2, 2, 256), p.as_dict()
+    rc, p = plan(48, 3584, 14336)
+    assert rc == 0 and (p.family, p.m_block, p.splitk) == (2, 1, 4), p.as_dict()
+    rc, p = plan(32, 8192, 8192)                                  # K = 8192: lane sharing stays (measured in round 3)
+    assert rc == 0 and p.family == 2 and p.m_block == 2 and p.splitk == 1, p.as_dict()
+    # 3-bit blocks x UNEVEN K slices (K = 3584 = 3 x 1024 + 512), the cheapest candidate, combined in the launch
+    rc, p = plan(128, 14336, 3584, bits=3, tid=5, dtype=1)
+    assert rc == 0 and (p.family, p.m_block, p.splitk, p.k_per_split, p.grid, p.splitk_mode) == (3, 5, 4, 1024, 224, 1), p.as_dict()
+    rc, p = plan(128, 8192, 8192, bits=3, tid=4, dtype=1)         # 64-row blocks x 4 slices beat 128-row blocks x 4 here: reduce launch
+    assert rc == 0 and (p.family, p.m_block, p.splitk, p.grid, p.splitk_mode) == (3, 12, 4, 256, 0), p.as_dict()
+    # skinny 3-bit blocks up to M = 48 only where their grid fills 80 % of the CUs
+    rc, p = plan(48, 8192, 8192, bits=3, tid=4, dtype=1)
+    assert rc == 0 and (p.family, p.m_block, p.grid) == (3, 12, 256), p.as_dict()
+    rc, p = plan(48, 10240, 8192, bits=3, tid=4, dtype=1)
+    assert rc == 0 and p.family == 2, p.as_dict()
+    # the lean decode kernel: K = 3584 (7 pieces), K = 8192 for two rows on >= 80 % of a round, K = 2048 two rows up to two rounds
+    rc, p = plan(1, 4096, 3584)
+    assert rc == 0 and (p.family, p.one_shot, p.waves, p.kw, p.ring_depth, p.grid) == (0, 4, 4, 1, 7, 256), p.as_dict()
+    rc, p = plan(2, 3584, 8192)
+    assert rc == 0 and (p.one_shot, p.waves, p.kw, p.ring_depth, p.m_block, p.grid) == (4, 8, 2, 8, 2, 224), p.as_dict()
+    assert plan(1, 3584, 8192)[1].one_shot != 4 and plan(2, 2048, 8192)[1].one_shot != 4
+    rc, p = plan(2, 8192, 2048)
+    assert rc == 0 and (p.one_shot, p.grid) == (4, 512), p.as_dict()
+    assert plan(4, 8192, 2048)[1].one_shot != 4 and plan(2, 16384, 2048)[1].one_shot != 4
+
