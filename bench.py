@@ -16,6 +16,9 @@ Rank 0 prints ONE JSON line (contract in the task description) carrying
 stream) and `cpu_baseline` (the CPU oracle = the reference's test formula,
 dequant + torch.mm, timed on this host's cores).
 
+`--gpus N` under a launcher (the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+must agree with WORLD_SIZE; with no launcher around it the script starts the N ranks itself (re-exec under
+torch.distributed.run, rendezvous on 127.0.0.1).  The line carries the rank count summed over RCCL.
 N > 1 (one process per GPU, RCCL): the headline stays the same workload - N
 independent replicas, no collective, barrier + max-over-ranks, `value` = N x
 bytes / time, "scaling": "weak" - so that the per-N values are comparable.
@@ -351,9 +354,49 @@ def tp_mlp_pair(world, rank, device, dist, pairs=50, warmup=5):
             "template_ids": [up.template_id, down.template_id]}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks here - replace this
+    process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per
+    GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Under a launcher (the driver's torchrun
+    line) WORLD_SIZE is set and this is never reached."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+    env["FLUTE_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def _dry_run_ranks(args, world, rank):
+    """FLUTE_BENCH_DRYRUN=1 (tests/test_host.py, no GPU): the rank plumbing only - every rank joins a gloo group, the
+    rank count the process group reports and a sum of ones over the ranks go into the line.  No kernel runs and the line
+    says so (`dry_run`); never a measurement."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    ones = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ones)
+    assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_in_group": dist.get_world_size(),
+                          "ranks_counted_by_allreduce": int(ones.item()),
+                          "self_launched": os.environ.get("FLUTE_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE, else 1); with no launcher around it the script "
+                         "starts the ranks itself")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-extras", action="store_true")
@@ -363,9 +406,17 @@ def main():
                          "candidate launches out of the kernel trace)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        _self_launch(args.gpus)                      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("FLUTE_BENCH_DRYRUN") == "1":
+        return _dry_run_ranks(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -379,6 +430,7 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
         def sync():
             dist.barrier(device_ids=[local_rank])
@@ -400,8 +452,13 @@ def main():
     headline_timing = dict(LAST_TIMING)
     eager_ms = time_eager(layer, min(args.steps, 500), 10)
     t = torch.tensor([ev_ms, wall_ms, headline_timing["events_ms"]], device=device, dtype=torch.float64)
+    ranks_counted = 1
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, device=device, dtype=torch.int64)
+        dist.all_reduce(ones)                           # every rank adds 1 over RCCL: the rank count the line reports
+        ranks_counted = int(ones.item())
+        assert ranks_counted == args.gpus, (ranks_counted, args.gpus)
     ev_ms, wall_ms, hip_events_ms = t.tolist()
     ms_per_step = ev_ms / args.steps
     bytes_step = layer.bytes()
@@ -602,7 +659,8 @@ def main():
                                      "pmc_source": "profiles/" + os.path.basename(mp[-1])})
         out = {
             "metric": replicas["metric"],
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "ranks_counted_over_rccl": ranks_counted,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random codes/scales, NF4 table, X=randn/100; "

@@ -188,3 +188,30 @@ def test_shipped_tuned_table_is_consistent():
     # answered from the table: no CUDA device is touched
     tid = tune._tune(1, 4096, 4096, 4, 64, 256, torch.float16, torch.device("cpu"))
     assert tid == tune.lookup_tuned(1, 4096, 4096, 4, 64, 256, torch.float16)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher around it must come up as two ranks (the flag was parsed and
+    never read, so the first multi-GPU record would have been one rank).  FLUTE_BENCH_DRYRUN=1 stops each rank after the
+    process-group plumbing (gloo, no GPU here): the line carries the group's size and a sum of ones over the ranks.  And a
+    launcher whose rank count disagrees with --gpus is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FLUTE_BENCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_in_group"] == 2 and out["ranks_counted_by_allreduce"] == 2
+    assert out["self_launched"] is True and out["dry_run"] is True
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE=2" in (p2.stderr + p2.stdout)
