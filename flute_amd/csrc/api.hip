@@ -41,8 +41,8 @@ Ovr ovr_of(const flute_overrides* o) {
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (qgemm_block.h)
 constexpr int kFamilySkinny = 5;                // registers-only MFMA kernel for 3 <= M <= 32 (qgemm_skinny.h)
-constexpr int kFamilySplitK = 6;
-constexpr int kFamilyFastM = 7;                 // lean MFMA decode kernel: 4 unit rows x all of K per workgroup, M <= 16 (qgemm_fastm.h)                // 128 x 128 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
+constexpr int kFamilySplitK = 6;                // 128 / 64 x 128 / 64 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
+constexpr int kFamilyFastM = 7;                 // lean MFMA decode kernel: 4 unit rows x all of K per workgroup, M <= 16 (qgemm_fastm.h)
 // Workspace layout (every kernel): [0, kXwgFlagBytes) tile state words of the in-launch reductions (xwg.h; zero between
 // calls), fp32 slabs behind them.  A planner sees the room behind the state words only.
 size_t slab_room(size_t workspace_bytes) { return workspace_bytes > kXwgFlagBytes ? workspace_bytes - kXwgFlagBytes : 0; }
@@ -408,17 +408,20 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     const int g = 1 << lg, G = K >> lg;
     if (G % 8 || N % 128 || K % 128) return FLUTE_ERR_SHAPE;
     if ((size_t)(M + 128) * K * 2 >= (size_t)0xfffffff0u || (size_t)N * G * 2 >= (size_t)0xfffffff0u) return FLUTE_ERR_SHAPE;
-    const int align = 2 * std::max(64, g);
     // Row tiles per workgroup: 8 (128-row tiles) or 4 (64-row tiles: twice the tiles, half the slab per slice, every weight
-    // dequantised by twice as many workgroups); override m_tiles = 8 / 4 fixes it, else both are priced.
-    auto tiles_of = [&](int rt) { return (long)ceil_div(M, rt * 16) * (N / 128); };
-    auto slab_of = [&](int rt) { return (long)rt * 8192; };      // fp32 partial tile in fragment order: 64 / 32 KB
-    auto legal = [&](int sk, int rt) {
+    // dequantised by twice as many workgroups); override m_tiles = 8 / 4 fixes it, else both are priced.  K parts per workgroup
+    // (round 6): 2 (128-column tiles: four column groups x two K halves) or - 64-row tiles only - 4 (64-column tiles: two column groups
+    // x four K quarters: twice the tiles with NO more K slices, i.e. M = 256 on 4096 x 4096 as 256 workgroups without a seam; twice
+    // the activation bytes per workgroup); override kw = 2 / 4 fixes it.
+    auto tiles_of = [&](int rt, int kp) { return (long)ceil_div(M, rt * 16) * (N / (256 / kp)); };
+    auto slab_of = [&](int rt, int kp) { return (long)rt * 16384 / kp; };      // fp32 partial tile in fragment order: 8 waves x rt / kp row tiles x 2 KB
+    auto legal = [&](int sk, int rt, int kp) {
+        const int align = kp * std::max(64, g);                // every K part: whole 64-k steps and whole groups
         if (sk < 1 || sk > 16 || K % sk || (K / sk) % align) return false;
-        if (tiles_of(rt) > kXwgMaxTiles) return false;
-        const int gh = (K / sk / 2) >> lg;                     // groups per K half
-        if (gh + ((gh % 8) ? 7 : 0) > 32) return false;
-        const size_t slabs = (size_t)sk * tiles_of(rt) * slab_of(rt);
+        if (tiles_of(rt, kp) > kXwgMaxTiles) return false;
+        const int gw = (K / sk) >> lg;                         // groups of a workgroup's K range: one scale image of eight 8-group blocks per column group
+        if (gw + ((gw % 8) ? 7 : 0) > 64) return false;
+        const size_t slabs = (size_t)sk * tiles_of(rt, kp) * slab_of(rt, kp);
         if (sk > 1 && (slabs > slab_room(workspace_bytes) || slabs >= ((size_t)1 << 31))) return false;
         return true;
     };
@@ -427,25 +430,34 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     // 32.9 on 172, 39.3 on 224, 40.3 on 256 at K = 4096 - the more of the chip is busy the slower) or 0.44 .. 0.52 us (64-row
     // tiles: 23.9 us on 128 CUs, 26.5 on 256); the seam grows with the MB published write-through (E form at 2 slices
     // ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
-    auto model_us = [&](int sk, int rt) {
-        const long wgs = tiles_of(rt) * sk;
+    auto model_us = [&](int sk, int rt, int kp) {
+        const long wgs = tiles_of(rt, kp) * sk;
         const long rounds = (wgs + num_sms - 1) / num_sms;
         const double fill = std::min(1.0, (double)wgs / num_sms);
-        const double steps = (double)K / sk / 128.0;           // 64-k steps of a K half
-        const bool eform = sk == 2 || (sk == 4 && rt == 8);
-        const double mb = sk == 1 ? 0.0 : (double)wgs * (slab_of(rt) * 1e-6) * (eform ? (sk - 1.0) / sk : 1.0);
+        const double steps = (double)K / sk / (64.0 * kp);     // 64-k steps of a K part
+        const int hr = rt / kp;
+        const bool eform = (sk == 2 && hr % 2 == 0) || (sk == 4 && hr % 4 == 0);
+        const double mb = sk == 1 ? 0.0 : (double)wgs * (slab_of(rt, kp) * 1e-6) * (eform ? (sk - 1.0) / sk : 1.0);
         // (L form on 32-KB slabs, measured at M = 48 .. 96: 2.2 us at four slices / 3.4 at eight of 8.4 MB - profiles/r04/splitk_64_row_tiles_below_m128.json)
-        const double seam = sk == 1 ? 0.0 : (sk == 2 ? 1.0 + 0.15 * mb : (rt == 4 ? 1.5 + 0.15 * mb : 1.5 + 0.5 * mb));
+        const double seam = sk == 1 ? 0.0 : (sk == 2 && eform ? 1.0 + 0.15 * mb : (rt == 4 ? 1.5 + 0.15 * mb : 1.5 + 0.5 * mb));
         const double step = rt == 8 ? 0.65 + 0.31 * fill * fill * fill : 0.44 + 0.08 * fill * fill * fill;
+        // four K parts (64 x 64 tiles, round 6; tools/splitk_lab.py time_kp4, profiles/r06/call1_*.log, call16_*.log): a round costs 6.0 us
+        // + 0.6 us per step whatever share of the chip is busy (16 steps: 15.5 us on 256 CUs, 15.4 on 128, 15.5 on 64; 32 steps 25.1;
+        // 8 steps + the L-form seam of two slices 12.6)
+        if (kp == 4) return rounds * (6.0 + steps * 0.6) + seam;
         return rounds * (9.5 + steps * step) + seam;
     };
-    struct Cand { double us; int sk, rt; };
+    struct Cand { double us; int sk, rt, kp; };
     std::vector<Cand> c;
-    for (int rt : {8, 4}) {
-        if ((ov.m_tiles == 8 || ov.m_tiles == 4) && rt != ov.m_tiles) continue;
-        for (int sk = 1; sk <= 16; ++sk) {
-            if (ov.splitk > 0 && sk != ov.splitk) continue;
-            if (legal(sk, rt)) c.push_back(Cand{model_us(sk, rt), sk, rt});
+    for (int kp : {2, 4}) {
+        if ((ov.kw == 2 || ov.kw == 4) && kp != ov.kw) continue;
+        for (int rt : {8, 4}) {
+            if ((ov.m_tiles == 8 || ov.m_tiles == 4) && rt != ov.m_tiles) continue;
+            if (kp == 4 && rt != 4) continue;                  // four K parts: 64-row tiles only (LDS)
+            for (int sk = 1; sk <= 16; ++sk) {
+                if (ov.splitk > 0 && sk != ov.splitk) continue;
+                if (legal(sk, rt, kp)) c.push_back(Cand{model_us(sk, rt, kp), sk, rt, kp});
+            }
         }
     }
     if (c.empty()) return FLUTE_ERR_SHAPE;
@@ -455,14 +467,22 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     memset(p, 0, sizeof(*p));
     p->family = kFamilySplitK;
     // four loader waves beside the eight compute waves (round 4: K = 4096 per workgroup 34.1 -> 30.3 us on 64 CUs, 35.2 -> 32.9 on
-    // 172, 41.8 -> 40.3 on 256); override waves = 8: the variant without them
-    const int ldw = (ov.waves == 8) ? 0 : 4;
-    p->m_block = 0; p->m_tiles = best.rt; p->slabs_per_wave = 1; p->waves = 8 + ldw; p->kw = 2;
+    // 172, 41.8 -> 40.3 on 256; the variant without them - override waves = 8 - was dropped in round 6)
+    if (ov.waves > 0 && ov.waves != 12) return FLUTE_ERR_SHAPE;
+    const int ldw = SK_LOADERS;
+    // m_block: row tiles of a column tile per XCD group (block order of launches without K slices); 2 since round 4, override 1 / 2 / 4 / 8
+    {
+        const int tm = ceil_div(M, best.rt * 16);
+        int E = (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4 || ov.m_block == 8) ? ov.m_block : 2;
+        if (best.sk != 1 || tm % E || ((tm / E) & (tm / E - 1))) E = 1;
+        p->m_block = E;
+    }
+    p->m_tiles = best.rt; p->slabs_per_wave = 1; p->waves = 8 + ldw; p->kw = best.kp;
     p->splitk = best.sk; p->k_per_split = K / best.sk;
-    p->grid = (unsigned)(tiles_of(best.rt) * best.sk); p->block = (unsigned)(512 + 64 * ldw);
-    p->lds_bytes = (size_t)splitk_lds_bytes(bits, best.rt); p->lut_copies = 32;
+    p->grid = (unsigned)(tiles_of(best.rt, best.kp) * best.sk); p->block = (unsigned)(512 + 64 * ldw);
+    p->lds_bytes = (size_t)splitk_lds_bytes(bits, best.rt, best.kp); p->lut_copies = 32;
     p->splitk_mode = best.sk > 1 ? 1 : 0;
-    p->workspace_needed = best.sk > 1 ? (size_t)best.sk * tiles_of(best.rt) * slab_of(best.rt) + kXwgFlagBytes : 0;
+    p->workspace_needed = best.sk > 1 ? (size_t)best.sk * tiles_of(best.rt, best.kp) * slab_of(best.rt, best.kp) + kXwgFlagBytes : 0;
     return FLUTE_OK;
 }
 
@@ -779,7 +799,12 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         flute_plan q;
         double sk_us = 0.0;
         // (one round of workgroups only: multi-round launches are left to the tuner's Stages-5 ids until measured)
-        if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, &q, 0, &sk_us) == FLUTE_OK && sk_us < 0.92 * alt_us &&
+        // (round 6: 64 x 64 tiles - four K parts per workgroup - that fill at least half the chip are priced against the per-wave kernel
+        // WITH its fixed part, which the TFLOP/s model above lacks: measured - modelled 3.2 .. 5.7 us on 4096-wide layers, 10 on
+        // 2048 x 8192; profiles/r06/call17_automatic_plan_vs_forced.log: M = 128 on 4096^2 13.1 against 14.9 us, M = 192 15.1 / 18.8, M = 512 on
+        // 2048 x 4096 15.8 / 19.9, M = 256 on 2048 x 8192 18.0 / 26.6, M = 48 on 3584 x 14336 16.7 / 21.6, M = 33 on 8192^2 17.7 / 26.1)
+        if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, &q, 0, &sk_us) == FLUTE_OK &&
+            sk_us < ((q.kw == 4 && (long)q.grid * 2 >= (long)num_sms) ? alt_us + 4.0 : 0.92 * alt_us) &&
             (long)q.grid <= (long)num_sms && q.lds_bytes <= (size_t)kMaxLds) {
             *p = q;
             return FLUTE_OK;
@@ -1333,12 +1358,16 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         b.M = M; b.N = N; b.K = K; b.G = K / group_size; b.lg = ilog2(group_size);
         b.tiles_m = ceil_div(M, p.m_tiles * 16);
         b.splitk = p.splitk; b.k_per_split = p.k_per_split;
-        b.pair_lg = -1; b.pair_c8 = 0;
-        if (p.splitk == 1 && b.tiles_m >= 2 && b.tiles_m % 2 == 0 && ((b.tiles_m / 2) & (b.tiles_m / 2 - 1)) == 0) {
-            b.pair_lg = ilog2(b.tiles_m / 2);
-            b.pair_c8 = ((b.tiles_m / 2) * (N / 128)) & ~7;
+        b.pair_lg = -1; b.pair_c8 = 0; b.pair_e = 0;
+        const int tile_cols = 256 / p.kw;                      // kw = K parts per workgroup: 128- / 64-column tiles
+        // m_block = E: the E row tiles of a column tile that run as consecutive blocks of ONE XCD (0 / 1: natural order)
+        const int E = p.m_block;
+        if (p.splitk == 1 && E >= 2 && b.tiles_m % E == 0 && ((b.tiles_m / E) & (b.tiles_m / E - 1)) == 0) {
+            b.pair_e = ilog2(E);
+            b.pair_lg = ilog2(b.tiles_m / E);
+            b.pair_c8 = ((b.tiles_m / E) * (N / tile_cols)) & ~7;
         }
-        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.waves == 12 ? 4 : 0, p.m_tiles);
+        SplitKKernel fn = splitk_kernel(num_bits, dtype, t.tile_p, p.m_tiles, p.kw);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         void* kargs[] = {&b};

@@ -43,7 +43,7 @@ BlockKernel block_kernel_b3(int dtype, int tile_p, int cfg);
 // split-K block kernel (qgemm_splitk.h): 128 x 128 tiles, K split over workgroups, combined in the launch (xwg.h)
 struct SplitKArgs;
 typedef void (*SplitKKernel)(const SplitKArgs);
-SplitKKernel splitk_kernel(int bits, int dtype, int tile_p, int ldw, int rt);   // ldw: loader waves (0 / 4), rt: row tiles per workgroup (8 / 4)
+SplitKKernel splitk_kernel(int bits, int dtype, int tile_p, int rt, int kp);   // rt: row tiles per workgroup (8 / 4), kp: K parts per workgroup (2; 4 with rt 4)
 // MFMA kernel (qgemm_tile.h): r lanes share one unit's words (1, 2, 4; b=3: 1), mt 16-row tiles per wave
 QGemmKernel tile_kernel_b4(int dtype, int tile_p, int r, int mt, int sw);   // sw: slabs per wave (1, 2)
 QGemmKernel tile_kernel_b3(int dtype, int tile_p, int r, int mt);

@@ -52,8 +52,10 @@ def test_error_messages_match_reference_prefixes():
         _lib.check(-3)
 
 
-def plan(M, N, K, bits=4, g=64, tid=16, sms=256, ws=64 << 20, dtype=0):
+def plan(M, N, K, bits=4, g=64, tid=16, sms=256, ws=64 << 20, dtype=0, ovr=None):
     p = _lib.Plan()
+    if ovr is not None:
+        return _lib.get().flute_qgemm_plan_ex(dtype, bits, g, M, N, K, tid, sms, ws, ovr, p), p
     rc = _lib.get().flute_qgemm_plan(dtype, bits, g, M, N, K, tid, sms, ws, p)
     return rc, p
 
@@ -70,6 +72,10 @@ def test_plan_families_and_invariants():
                 want = 3                             # 3 bits: the per-wave kernel is slow enough that 128 blocks already win
             if bits != 3 and M == 1000:
                 want = 6                             # 2 / 4 bits: 8 x 32 tiles of 128 x 128, one per CU (qgemm_splitk.h, round 4)
+            if bits != 3 and M == 256:
+                want = 6                             # ... and 4 x 64 tiles of 64 x 64 over all of K (four K parts per workgroup, round 6)
+            if bits == 4 and M == 64:
+                want = 6                             # ... x 4 K slices at M = 64 (4 bits from M = 33)
             if bits == 4 and 5 <= M <= 16:
                 want = 7                             # 4 bits, K = 4096, one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
@@ -77,7 +83,7 @@ def test_plan_families_and_invariants():
                 assert (p.grid, p.waves, p.block, p.lds_bytes, p.splitk, p.workspace_needed) == (256, 8, 512, 32768 + 32 * 4096, 1, 0)
                 continue
             if p.family == 6:
-                assert (p.grid, p.block, p.splitk, p.workspace_needed) == (256, 768, 1, 0)      # 8 compute + 4 loader waves
+                assert (p.grid, p.block) == (256, 768) and (p.splitk, p.workspace_needed) in ((1, 0), (4, 4 * 64 * 16384 + 65536))      # 8 compute + 4 loader waves
                 continue
             if p.family == 2:
                 assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2)
@@ -122,7 +128,7 @@ def test_plan_families_and_invariants():
     rc, p = plan(1024, 4096, 4096)
     assert rc == 0 and p.family == 6 and p.grid == 256 and p.splitk == 1      # too few 128 / 256 x 256 blocks: 128 x 128 tiles (round 4; the per-wave kernel before)
     rc, p = plan(256, 4096, 4096)
-    assert rc == 0 and p.family == 2                    # four K slices per tile would be needed: the seam costs more than it saves
+    assert rc == 0 and p.family == 6 and (p.grid, p.splitk, p.kw, p.m_tiles, p.workspace_needed) == (256, 1, 4, 4, 0)   # round 6: 64 x 64 tiles over all of K, four K parts per workgroup, no seam (rounds 4 / 5: the per-wave kernel - four K slices per 128 x 128 tile cost more than they saved)
     rc, p = plan(256, 11008, 4096)
     assert rc == 0 and p.family == 6 and (p.grid, p.splitk) == (172, 1)
     rc, p = plan(256, 8192, 8192)
@@ -144,11 +150,11 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 2                    # ... which keeps the small layers (30.5 us against 32.5)
     # 4-bit layers below M = 128 (round 4): 64-row tiles x K slices where the model beats the per-wave kernel, one round of workgroups
     rc, p = plan(64, 8192, 8192)
-    assert rc == 0 and (p.family, p.m_tiles, p.splitk, p.grid, p.splitk_mode) == (6, 4, 4, 256, 1)
+    assert rc == 0 and (p.family, p.m_tiles, p.kw, p.splitk, p.grid, p.splitk_mode) == (6, 4, 4, 2, 256, 1)     # round 6: 64 x 64 tiles x 2 slices (19.7 us; 64 x 128 x 4 slices 20.5)
     rc, p = plan(64, 28672, 8192)
     assert rc == 0 and p.family == 2                    # two rounds of tiles: per-wave kernel (two slabs per wave)
     rc, p = plan(33, 8192, 8192)
-    assert rc == 0 and (p.family, p.m_tiles, p.splitk) == (6, 4, 4)
+    assert rc == 0 and (p.family, p.m_tiles, p.kw, p.splitk) == (6, 4, 4, 2)
     rc, p = plan(32, 8192, 8192)
     assert rc == 0 and p.family == 2
     rc, p = plan(96, 8192, 8192, bits=2, tid=0)
@@ -317,14 +323,15 @@ def test_plan_invariants_over_random_shapes():
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
             assert bits != 3 or p.m_block == 1, what
         elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
-            assert p.m_tiles in (8, 4), what                      # 128- / 64-row tiles
-            tiles = -(-M // (p.m_tiles * 16)) * (N // 128)
+            assert p.m_tiles in (8, 4) and p.kw in (2, 4) and (p.kw == 2 or p.m_tiles == 4), what      # 128- / 64-row tiles; K parts per workgroup (round 6: 4 = 64-column tiles)
+            tiles = -(-M // (p.m_tiles * 16)) * (N // (256 // p.kw))
             assert bits in (2, 4) and M >= (33 if bits == 4 else 65) and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
-            assert p.k_per_split * p.splitk == K and p.k_per_split % (2 * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
-            gh = p.k_per_split // 2 // g
-            assert gh + (7 if gh % 8 else 0) <= 32, what
-            assert p.splitk_mode == (1 if p.splitk > 1 else 0) and p.workspace_needed == (p.splitk * tiles * p.m_tiles * 8192 + 65536 if p.splitk > 1 else 0), what
-            assert p.lds_bytes == (128 << (2 * bits)) + 6 * p.m_tiles * 2048 + 16384, what
+            assert p.k_per_split * p.splitk == K and p.k_per_split % (p.kw * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
+            gw = p.k_per_split // g                               # one scale image of eight 8-group blocks per column group
+            assert gw + (7 if gw % 8 else 0) <= 64, what
+            slab = p.m_tiles * 16384 // p.kw                       # 8 waves x m_tiles / kw row tiles x 2 KB
+            assert p.splitk_mode == (1 if p.splitk > 1 else 0) and p.workspace_needed == (p.splitk * tiles * slab + 65536 if p.splitk > 1 else 0), what
+            assert p.lds_bytes == (128 << (2 * bits)) + p.kw * 3 * p.m_tiles * 2048 + (8 // p.kw) * 4096, what
         else:                                                     # block kernels
             assert p.family == 3 and p.m_block in (4, 5, 9, 10, 12) and p.block == 512, what
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
@@ -416,7 +423,9 @@ def test_round5_planner_rules():
     # a grid K split instead of more lane sharing on deep layers (K >= 10240: two slices, K >= 12288: four)
     rc, p = plan(4, 4096, 11008)
     assert rc == 0 and (p.family, p.m_block, p.splitk, p.grid) == (2, 2, 2, 256), p.as_dict()
-    rc, p = plan(48, 3584, 14336)
+    rc, p = plan(48, 3584, 14336)                                 # (round 6: 64 x 64 tiles x 4 slices are faster still - 16.7 against 21.6 us; by override the rule stands)
+    assert rc == 0 and (p.family, p.m_tiles, p.kw, p.splitk, p.grid) == (6, 4, 4, 4, 224), p.as_dict()
+    rc, p = plan(48, 3584, 14336, ovr=_lib.Overrides(family=2))
     assert rc == 0 and (p.family, p.m_block, p.splitk) == (2, 1, 4), p.as_dict()
     rc, p = plan(32, 8192, 8192)                                  # K = 8192: lane sharing stays (measured in round 3)
     assert rc == 0 and p.family == 2 and p.m_block == 2 and p.splitk == 1, p.as_dict()

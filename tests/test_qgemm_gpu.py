@@ -657,25 +657,27 @@ def test_splitk_block_kernel(env):
             ref = X.float() @ What
             ref1 = (table.float()[W.long()] * torch.repeat_interleave(S.float(), g, dim=1).T)[ks].to(dtype)
             ran = set()
-            for sk, rt in [(sk, rt) for sk in (1, 2, 3, 4, 6, 8, 16) for rt in (8, 4)]:      # 128- and 64-row tiles
-                ovr = dev.Overrides(family=6, splitk=sk, m_tiles=rt)
+            # 128- and 64-row tiles x two K parts per workgroup, 64-row tiles x four K parts (64-column tiles, round 6)
+            for sk, rt, kp in [(sk, rt, kp) for sk in (1, 2, 3, 4, 6, 8, 16) for (rt, kp) in ((8, 2), (4, 2), (4, 4))]:
+                ovr = dev.Overrides(family=6, splitk=sk, m_tiles=rt, kw=kp)
                 try:
                     plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
                 except RuntimeError:
                     continue                                      # not a legal split of this K (qgemm_splitk.h's host contract)
-                assert plan["family"] == 6 and plan["splitk"] == sk and plan["m_tiles"] == rt and plan["waves"] == 12
-                assert plan["grid"] == -(-M // (16 * rt)) * (N // 128) * sk
+                assert plan["family"] == 6 and plan["splitk"] == sk and plan["m_tiles"] == rt and plan["kw"] == kp and plan["waves"] == 12
+                assert plan["grid"] == -(-M // (16 * rt)) * (N // (256 // kp)) * sk
                 ran.add(sk)
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
                 out2 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr)
-                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, sk, rt)
-                assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk, rt)
-                assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk, rt)
-                assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk, rt)
-                if M in (130, 700) and sk in (1, 2, 3):              # the variant without loader waves: the same numbers
-                    o8 = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=6, splitk=sk, m_tiles=rt, waves=8))
-                    assert torch.equal(o8, out), (bits, tile_p, g, dtype, K, N, M, sk)
+                assert rel_err(out.cpu(), ref) < tol_of(dtype), (bits, tile_p, g, dtype, K, N, M, sk, rt, kp)
+                assert torch.equal(out1.cpu(), ref1), (bits, tile_p, g, dtype, K, N, M, sk, rt, kp)
+                assert torch.equal(out, out2), (bits, tile_p, g, dtype, K, N, M, sk, rt, kp)
+                assert _state_words_clean(env), (bits, tile_p, g, dtype, K, N, M, sk, rt, kp)
+                if M == 256 and sk == 1 and rt == 4:                 # the XCD-aware block orders (m_block = row tiles per group) are the same numbers
+                    for mb in (1, 2, 4):
+                        om = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, dev.Overrides(family=6, splitk=1, m_tiles=4, kw=kp, m_block=mb))
+                        assert torch.equal(om, out), (bits, tile_p, g, dtype, K, N, kp, mb)
             assert 1 in ran or g == 32 and K > 2048, (K, g, ran)
             assert len(ran) >= 3, (K, g, ran)
     # the planner takes it by itself where it was measured faster (profiles/r04): one workgroup per tile on the MLP widths
@@ -685,7 +687,8 @@ def test_splitk_block_kernel(env):
     assert p["family"] == 6 and (p["grid"], p["splitk"]) == (256, 1), p
     p = dev.get_plan(256, 8192, 8192, 4, 64, 16, 256, torch.float16)
     assert p["family"] == 6 and (p["grid"], p["splitk"]) == (256, 2), p
-    assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2      # four slices: the seam costs more than it saves
+    p = dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)                        # round 6: 64 x 64 tiles over all of K, no seam (rounds 4 / 5: the per-wave kernel)
+    assert p["family"] == 6 and (p["grid"], p["splitk"], p["kw"], p["m_tiles"]) == (256, 1, 4, 4), p
     # the automatic plan through the operator, at a BASELINE shape, against the per-wave kernel
     bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 4096, 11008
     W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=11)

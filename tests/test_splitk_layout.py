@@ -45,48 +45,86 @@ def test_activation_pieces_land_where_the_fragments_read_them():
                 assert len({(addrs[l] // 16) % 16 for l in grp}) == 16, (R, h)
 
 
+def weight_row(r16, U):
+    """qgemm_splitk.h (round 6): MFMA weight row r16 = (b3 b2 b1 b0) of a column tile -> (unit, field): lane bit 1 is a field bit."""
+    return (((r16 >> 2) % (U // 2)) << 1) | (r16 & 1), ((r16 >> 2) // (U // 2)) * 2 + ((r16 >> 1) & 1)
+
+
 @pytest.mark.parametrize("bits,tile_p", [(4, 32), (4, 64), (2, 32), (2, 64)])
-def test_scale_image_and_output_columns(bits, tile_p):
+@pytest.mark.parametrize("kp", [2, 4])
+def test_scale_image_and_output_columns(bits, tile_p, kp):
     J = 16 // bits
     U = 32 // J
     FPT = 16 // U
-    N, G, lg = 512, 40, 6
+    N, G, lg = 512, 72, 6
     S = np.arange(N * G, dtype=np.int64).reshape(N, G)
 
     def unit_col0(u):
         return (u // tile_p) * (J * tile_p) + (u % tile_p)
 
+    # every weight row of a column tile is one (unit, field), every (unit, field) exactly once
+    assert sorted(weight_row(r, U) for r in range(16)) == sorted((u, f) for u in range(U) for f in range(FPT))
+    bpw = 8 // kp
     for unit0 in (0, U * 5):
-        for kbeg in (0, 512, 1600):                                   # first group 0, 8, 25
-            g0e = (kbeg >> lg) & ~7
-            img = np.full(2048 // 2, -1, dtype=np.int64)
-            for r in range(2):
-                for lane in range(64):
-                    cl = lane & 31
-                    col = unit_col0(unit0 + cl % U) + (cl // U) * tile_p
-                    g = g0e + (lane >> 5) * 8 + r * 16
-                    dst = (r * 1024 + lane * 16) // 2
-                    for e in range(8):
-                        img[dst + e] = S[col, g + e] if g + e < G else 0
+        for kwg in (0, 512, 1600):                                    # first group of the workgroup's K range: 0, 8, 25
+            g0e = (kwg >> lg) & ~7
+            img = np.full(4096 // 2, -1, dtype=np.int64)              # ONE image per column group: eight 8-group blocks x 32 columns x 16 B
+            for kh in range(kp):                                      # the KP waves of the group fetch 8 / KP blocks each
+                for r in range(bpw // 2):
+                    for lane in range(64):
+                        cl = lane & 31
+                        col = unit_col0(unit0 + cl % U) + (cl // U) * tile_p
+                        g = g0e + (kh * bpw + (lane >> 5)) * 8 + r * 16
+                        dst = ((kh * bpw + 2 * r) * 512 + lane * 16) // 2
+                        for e in range(8):
+                            img[dst + e] = S[col, g + e] if g + e < G else 0
+            assert (img >= 0).all()
             for lane in range(64):
                 r16 = lane & 15
-                u8, fsel = r16 % U, r16 // U
+                u8, fsel = weight_row(r16, U)
                 for t in range(2):
                     col = unit_col0(unit0 + u8) + (fsel + FPT * t) * tile_p    # weight row r16 of column tile t
-                    for k in range(kbeg, min(kbeg + 1024, G << lg), 32):
+                    for k in range(kwg, min(kwg + 2048, G << lg), 32):          # every 32-k half step of any K part
                         rel = (k >> lg) - g0e
-                        if rel >= 32:
+                        if rel >= 64:
                             break
                         a = (fsel * U + u8) * 16 + (rel >> 3) * 512 + (rel & 7) * 2 + t * 256
                         assert img[a // 2] == S[col, k >> lg], (lane, t, k)
-    # the epilogue's four consecutive columns: accumulator register j of lane (r16, q4) = weight row 4 q4 + j
+    # the epilogue: accumulator register j of lane (r16, q4) = weight row 4 q4 + j; after v_permlane16_swap of (j0, j2) and (j1, j3)
+    # between the lane rows q4, q4 ^ 1 every lane holds four consecutive columns: a = rows (a0, b0, a2, b2), b = rows (a1, b1, a3, b3)
+    regs = {q4: [weight_row(4 * q4 + j, U) for j in range(4)] for q4 in range(4)}
     for q4 in range(4):
-        c_unit = (4 * q4) % U
+        p = q4 ^ 1
+        if q4 % 2 == 0:
+            held = [regs[q4][0], regs[q4][1], regs[p][0], regs[p][1]]       # a keeps its even rows, b's even rows take a's odd rows
+        else:
+            held = [regs[p][2], regs[p][3], regs[q4][2], regs[q4][3]]
+        c_unit = ((q4 & ~1) % (U // 2)) * 2
+        c_field = (q4 // (U // 2)) * 2 + (q4 & 1)
         for t in range(2):
-            c0 = unit_col0(c_unit) + ((4 * q4) // U + FPT * t) * tile_p
-            for j in range(4):
-                rho = 4 * q4 + j
-                assert unit_col0(rho % U) + (rho // U + FPT * t) * tile_p == c0 + j
+            c0 = unit_col0(c_unit) + (c_field + FPT * t) * tile_p
+            for j, (u, f) in enumerate(held):
+                assert unit_col0(u) + (f + FPT * t) * tile_p == c0 + j, (q4, t, j)
+
+
+def test_weight_request_touches_two_lines_per_lane_quad():
+    """Round 6: lane (r16, q4) asks for chunk 4 ((r16 >> 1) & 1) + q4 of its unit's 128-B step piece - the four lanes of a quad are two
+    units x two half steps (two cache lines; rounds 4 / 5: four units = four lines) - and quad_perm [2h, 2h + 1, 2h, 2h + 1] hands
+    every lane the half step h of ITS unit."""
+    for U in (8, 4):
+        held = {}
+        for lane in range(64):
+            r16, q4 = lane & 15, lane >> 4
+            u8, _ = weight_row(r16, U)
+            held[lane] = (u8, (r16 >> 1) & 1, q4)                      # (unit row, half step, 16-B chunk of the half step)
+        for quad in range(16):
+            lines = {held[l][0] for l in range(4 * quad, 4 * quad + 4)}
+            assert len(lines) == 2
+        for h in (0, 1):
+            for lane in range(64):
+                src = (lane & ~3) | (2 * h + (lane & 1))
+                u8, _ = weight_row(lane & 15, U)
+                assert held[src] == (u8, h, lane >> 4)
 
 
 def _plan(M, N, K, bits=4, g=64, tid=16, ws=64 << 20, dtype=0, **ovr):
@@ -97,13 +135,15 @@ def _plan(M, N, K, bits=4, g=64, tid=16, ws=64 << 20, dtype=0, **ovr):
 
 def test_plan_family6():
     rc, p = _plan(256, 4096, 4096, family=6)
-    assert rc == 0 and p.family == 6 and p.block == 768 and p.waves == 12 and p.kw == 2      # 8 compute + 4 loader waves
-    rc8, p8 = _plan(256, 4096, 4096, family=6, waves=8)
-    assert rc8 == 0 and p8.block == 512 and p8.waves == 8                                    # the variant without loader waves
-    assert p.m_tiles == 4 and p.splitk == 2 and p.k_per_split == 2048 and p.grid == 256 and p.splitk_mode == 1     # 64-row tiles x two slices (measured 19.3 us; 128-row tiles 22.0)
+    assert rc == 0 and p.family == 6 and p.block == 768 and p.waves == 12 and p.kw == 4      # 8 compute + 4 loader waves; round 6: four K parts
+    assert _plan(256, 4096, 4096, family=6, waves=8)[0] != 0                                 # the variant without loader waves was dropped in round 6
+    assert p.m_tiles == 4 and p.splitk == 1 and p.k_per_split == 4096 and p.grid == 256 and p.splitk_mode == 0     # 64 x 64 tiles over all of K: no seam (15.5 us; 64 x 128 x two slices 18.3)
+    assert p.workspace_needed == 0 and p.lds_bytes == 32768 + 4 * 3 * 8192 + 2 * 4096 and p.m_block == 2
+    rc, p = _plan(256, 4096, 4096, family=6, kw=2)
+    assert rc == 0 and p.kw == 2 and p.m_tiles == 4 and p.splitk == 2 and p.k_per_split == 2048 and p.grid == 256 and p.splitk_mode == 1     # rounds 4 / 5: 64-row tiles x two slices
     assert p.workspace_needed == 2 * 128 * 32768 + (64 << 10) and p.lds_bytes == 32768 + 49152 + 16384   # 32 KB per 64-row tile and slice
     rc, p = _plan(256, 4096, 4096, family=6, m_tiles=8)
-    assert rc == 0 and p.m_tiles == 8 and p.splitk == 2 and p.grid == 128 and p.workspace_needed == 2 * 64 * 65536 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384
+    assert rc == 0 and p.m_tiles == 8 and p.kw == 2 and p.splitk == 2 and p.grid == 128 and p.workspace_needed == 2 * 64 * 65536 + (64 << 10) and p.lds_bytes == 32768 + 98304 + 16384
     assert _plan(256, 4096, 4096, family=6, splitk=16, m_tiles=8)[0] != 0     # 64 MiB of slabs + the state words: one page too many
     for sk in (1, 2, 4, 8, 16):
         rc, p = _plan(256, 4096, 4096, family=6, splitk=sk, m_tiles=8, ws=128 << 20)
@@ -114,7 +154,7 @@ def test_plan_family6():
     assert _plan(256, 4096, 4096, family=6, splitk=4, ws=1 << 20)[0] != 0   # slabs do not fit
     assert _plan(256, 4096, 4096, family=6, splitk=1, ws=0)[0] == 0
     assert _plan(256, 4096, 4096, bits=3, tid=0, family=6)[0] != 0     # 3 bits: other kernels
-    assert _plan(256, 4096, 4096, g=32, family=6, splitk=1)[0] != 0    # 64 groups per K half: more than four scale blocks
+    assert _plan(256, 4096, 4096, g=32, family=6, splitk=1)[0] != 0    # 128 groups per workgroup K range: more than eight scale blocks
     assert _plan(256, 4096, 4096, g=32, family=6, splitk=2)[0] == 0
     rc, p = _plan(256, 4096, 4096, g=256, family=6, splitk=8)           # K half = one 256-wide group
     assert rc == 0 and p.k_per_split == 512

@@ -355,10 +355,10 @@ def check_rt4():
             E = torch.zeros(M, K, device=d, dtype=dtype)
             E[torch.arange(M, device=d), ks] = 1
             for sk in (1, 2, 3, 4, 8):
-                for waves in (-1, 8):
+                for waves in (-1,):
                     rec = {"kind": "check_rt4", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "splitk": sk, "waves": waves}
                     try:
-                        ovr = dev.Overrides(family=6, splitk=sk, m_tiles=4, waves=waves)
+                        ovr = dev.Overrides(family=6, splitk=sk, m_tiles=4, waves=waves, kw=2)
                         try:
                             pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
                         except RuntimeError:
@@ -396,36 +396,117 @@ def time_rt4():
                 time_one(M, N, K, 4, f16, dict(family=6, splitk=sk, m_tiles=rt))
 
 
-rc = 0
-if "check_rt4" in what:
-    rc |= check_rt4()
-if "time_rt4" in what:
-    time_rt4()
-if "time_had" in what:
-    time_had()
-if "check_ldw" in what:
-    rc |= check_ldw()
-if "time_ldw" in what:
-    time_ldw()
-if "check_skinny" in what:
-    rc |= check_skinny()
-if "time_skinny" in what:
-    time_skinny()
-if "time_abl" in what:                                             # ablation builds (tools/splitk_ablate.sh): loop rates only
-    tag = os.path.basename(os.environ.get("FLUTE_AMD_LIB", "shipped"))
-    for sk in (1, 4):
-        time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
-    time_one(256, 11008, 4096, 4, f16, dict(family=6, splitk=1), tag=tag)
-    for sk in (2, 8):                                              # the seam's price: ablation 128 against the shipped library
-        time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
-    for (M, N, K, sk) in ((16, 4096, 4096, 4), (16, 4096, 4096, 2), (16, 8192, 4096, 2), (4, 4096, 4096, 4), (16, 2048, 8192, 8)):
-        time_one(M, N, K, 4, f16, dict(family=5, splitk=sk), tag=tag, steps=500)
-if "check" in what:
-    rc |= check()
-if "stress" in what:
-    rc |= stress()
-if "time" in what:
-    timing()
-if "time_more" in what:
-    timing(True)
-sys.exit(1 if rc else 0)
+def check_kp4():
+    """Four K parts per workgroup (override kw = 4: 64 x 64 tiles, round 6) on a subset of check()'s cases, with and without K slices."""
+    nfail = 0
+    for (bits, tile_p, g, dtype, K, N) in [(4, 32, 64, f16, 4096, 4096), (4, 64, 64, bf16, 2048, 1024), (4, 32, 128, f16, 3072, 512),
+                                           (2, 32, 64, f16, 4096, 2048), (2, 64, 128, bf16, 2048, 1024), (4, 32, 32, f16, 1024, 256),
+                                           (4, 32, 64, f16, 4096, 11008), (4, 64, 256, bf16, 4096, 256)]:
+        torch.manual_seed(K + N)
+        W = torch.randint(0, 2 ** bits, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(2 ** bits, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = tid_of(bits, tile_p)
+        Q = utils.pack(W, bits, [tid], num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        tol = 1e-3 if dtype == f16 else 4e-3
+        for M in (1, 60, 64, 130, 256, 700):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for sk in (1, 2, 3, 4, 8):
+                rec = {"kind": "check_kp4", "bits": bits, "tile_p": tile_p, "g": g, "dtype": str(dtype)[6:], "K": K, "N": N, "M": M, "splitk": sk}
+                try:
+                    ovr = dev.Overrides(family=6, splitk=sk, kw=4)
+                    try:
+                        pl = dev.get_plan(M, N, K, bits, g, tid, num_sms, dtype, ovr)
+                    except RuntimeError:
+                        continue
+                    assert pl["m_tiles"] == 4 and pl["kw"] == 4 and pl["grid"] == -(-M // 64) * (N // 64) * sk, pl
+                    o = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    o1 = dev.qgemm_planned(E, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    o2 = dev.qgemm_planned(X, Q, S, table, table2, ws, bits, g, tid, num_sms, ovr)
+                    torch.cuda.synchronize()
+                    err = ((o.float() - ref).norm() / ref.norm()).item()
+                    rec.update(err=err, onehot_exact=bool(torch.equal(o1, What[ks])), repeat_identical=bool(torch.equal(o, o2)), state_clean=state_clean())
+                    rec["ok"] = bool(err < tol and rec["onehot_exact"] and rec["repeat_identical"] and rec["state_clean"])
+                    if not rec["ok"]:
+                        bad = ((o.float() - ref).abs() > 0.05 * ref.abs().max()) | o.float().isnan()
+                        rec["nbad"] = int(bad.sum().item())
+                        rec["bad_rows"] = bad.any(1).nonzero().flatten()[:12].tolist()
+                        rec["bad_cols"] = bad.any(0).nonzero().flatten()[:16].tolist()
+                    if not rec["state_clean"]:
+                        ws[:65536].zero_()
+                except Exception as ex:  # noqa: BLE001
+                    rec.update(ok=False, error=str(ex)[:300])
+                if not rec["ok"]:
+                    nfail += 1
+                    emit(rec)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    emit({"kind": "check_kp4_summary", "failed": nfail})
+    return nfail
+
+
+def time_kp4():
+    for (M, N, K) in ((256, 4096, 4096), (192, 4096, 4096), (128, 4096, 4096), (64, 4096, 4096), (256, 2048, 8192), (128, 8192, 4096), (512, 2048, 4096),
+                      (64, 8192, 8192), (256, 11008, 4096)):
+        time_one(M, N, K, 4, f16, None)
+        for shp in (dict(family=6, splitk=1, kw=4), dict(family=6, splitk=2, kw=4), dict(family=6, splitk=2, kw=2, m_tiles=4), dict(family=6, splitk=1, kw=2, m_tiles=4),
+                    dict(family=6, splitk=1, kw=2, m_tiles=8)):
+            try:
+                dev.get_plan(M, N, K, 4, 64, tid_of(4, 32), num_sms, f16, dev.Overrides(**shp))
+            except RuntimeError:
+                continue
+            time_one(M, N, K, 4, f16, shp)
+    time_one(256, 4096, 4096, 4, bf16, dict(family=6, splitk=1, kw=4))
+    time_one(256, 4096, 4096, 4, bf16, None)
+    time_one(256, 4096, 4096, 2, f16, dict(family=6, splitk=1, kw=4))
+    time_one(256, 4096, 4096, 2, f16, None)
+
+
+def main():
+    rc = 0
+    if "check_kp4" in what:
+        rc |= check_kp4()
+    if "time_kp4" in what:
+        time_kp4()
+    if "check_rt4" in what:
+        rc |= check_rt4()
+    if "time_rt4" in what:
+        time_rt4()
+    if "time_had" in what:
+        time_had()
+    if "check_ldw" in what:
+        rc |= check_ldw()
+    if "time_ldw" in what:
+        time_ldw()
+    if "check_skinny" in what:
+        rc |= check_skinny()
+    if "time_skinny" in what:
+        time_skinny()
+    if "time_abl" in what:                                             # ablation builds (tools/splitk_ablate.sh): loop rates only
+        tag = os.path.basename(os.environ.get("FLUTE_AMD_LIB", "shipped"))
+        for sk in (1, 4):
+            time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
+        time_one(256, 11008, 4096, 4, f16, dict(family=6, splitk=1), tag=tag)
+        for sk in (2, 8):                                              # the seam's price: ablation 128 against the shipped library
+            time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=sk), tag=tag)
+        for (M, N, K, sk) in ((16, 4096, 4096, 4), (16, 4096, 4096, 2), (16, 8192, 4096, 2), (4, 4096, 4096, 4), (16, 2048, 8192, 8)):
+            time_one(M, N, K, 4, f16, dict(family=5, splitk=sk), tag=tag, steps=500)
+    if "check" in what:
+        rc |= check()
+    if "stress" in what:
+        rc |= stress()
+    if "time" in what:
+        timing()
+    if "time_more" in what:
+        timing(True)
+    sys.exit(1 if rc else 0)
+
+
+if __name__ == "__main__":
+    main()

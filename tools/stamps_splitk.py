@@ -19,10 +19,13 @@ from flute_amd import dev, utils  # noqa: E402
 d = torch.device("cuda:0")
 f16 = torch.float16
 out = []
-for (M, N, K, sk) in ((256, 4096, 4096, 4), (256, 4096, 4096, 2), (256, 4096, 4096, 1), (256, 4096, 4096, 8), (256, 11008, 4096, 1), (256, 11008, 4096, 2)):
+CASES = ((256, 4096, 4096, 4, -1), (256, 4096, 4096, 2, -1), (256, 4096, 4096, 1, -1), (256, 4096, 4096, 8, -1), (256, 11008, 4096, 1, -1), (256, 11008, 4096, 2, -1))
+if os.environ.get("STAMPS_KP4") == "1":      # round 6: four K parts per workgroup (64 x 64 tiles, no seam) against the two-slice plan
+    CASES = ((256, 4096, 4096, 1, 4), (256, 4096, 4096, 2, 2))
+for (M, N, K, sk, kw) in CASES:
     lay = bench.Layer(M, N, K, 4, 64, f16, d, 1 if os.environ.get("STAMPS_HOT") == "1" else bench.copies_for(N, K, 4))   # STAMPS_HOT=1: the weights stay cache-resident
     lay.template_id = 16
-    lay.ovr = dev.Overrides(family=6, splitk=sk)
+    lay.ovr = dev.Overrides(family=6, splitk=sk, kw=kw)
     plan = dev.get_plan(M, N, K, 4, 64, 16, lay.num_sms, f16, lay.ovr)
     nw = plan["grid"] * 8
     base = (65536 + sk * M * N * 4) // 8          # stamps sit behind splitk * M * N floats from the slab base (M = 256: whole tiles)
@@ -36,7 +39,7 @@ for (M, N, K, sk) in ((256, 4096, 4096, 4), (256, 4096, 4096, 2), (256, 4096, 40
     t0 = st[:, 0].min()
     us = (st - t0) / 100.0
     q = lambda x: [round(float(v), 2) for v in (x.min(), x.median(), x.max())]  # noqa: E731
-    r = {"hot": os.environ.get("STAMPS_HOT") == "1", "M": M, "N": N, "K": K, "splitk": sk, "grid": plan["grid"], "start[min,med,max]": q(us[:, 0]), "prologue": q(us[:, 1] - us[:, 0]),
+    r = {"hot": os.environ.get("STAMPS_HOT") == "1", "M": M, "N": N, "K": K, "splitk": sk, "kw": plan["kw"], "m_tiles": plan["m_tiles"], "grid": plan["grid"], "start[min,med,max]": q(us[:, 0]), "prologue": q(us[:, 1] - us[:, 0]),
          "mainloop": q(us[:, 2] - us[:, 1]), "exchange": q(us[:, 3] - us[:, 2])}
     if sk > 1:
         last = st[:, 9] == sk - 1
