@@ -662,6 +662,8 @@ def main():
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "ranks_counted_over_rccl": ranks_counted,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
+            "clock": headline_timing.get("clock"),            # what `value` was timed with; the HIP-event figure of the same replay follows
+            "value_hip_events": round(world * bytes_step / (hip_events_ms / args.steps * 1e-3) / 1e9, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
             "data": "synthetic (random codes/scales, NF4 table, X=randn/100; "
                     f"{len(layer.Q)} rotating weight copies > 256 MiB L3; caches flushed (untimed) before the timed replay)",

@@ -107,7 +107,8 @@ __device__ __forceinline__ uint32_t xwg_sweep(xwg_word* st, uint32_t nsl, uint32
         // (the launch traps and the stream reports an error): carrying on with an incomplete abandoned set would skip shares nobody
         // combined and reset state words an owner may still OR into - silent, persistent corruption of the shared workspace.
         bool done = false;
-        for (unsigned spin = 0; spin < ((kXwgSpinLimit > 4096u ? kXwgSpinLimit : 4096u) << 8); ++spin) {
+        // (~16 M polls, tens of seconds: an owner that was merely preempted - a debugger, a time-sliced GPU - is waited for)
+        for (unsigned spin = 0; spin < ((kXwgSpinLimit > 4096u ? kXwgSpinLimit : 4096u) << 12); ++spin) {
             w1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((((w1 | (w1 >> 16)) & want) == want)) { done = true; break; }
             __builtin_amdgcn_s_sleep(8);

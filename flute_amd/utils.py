@@ -40,9 +40,10 @@ def make_workspace_streamk(device: torch.device) -> torch.Tensor:
     output tile for the in-launch reductions - zero when a call starts and zero
     again when it ends, as the reference's barrier region
     (tile_scheduler_utils.hpp:196) -, the fp32 split-K slabs follow
-    (splitk*M*N*4 bytes for the two-launch form, [splitk][tile] x 64 KB in
-    MFMA-fragment order for the in-launch form; the planner only takes splits
-    that fit).  64 MiB replaces the reference's blocks*threads*2048-byte
+    (splitk*M*N*4 bytes for the two-launch form; for the in-launch form
+    [splitk][tile] slabs in MFMA-fragment order - 64 / 32 / 16 KB per 128 x 128 /
+    64 x 128 / 64 x 64 tile of the split-K block kernel, 128 KB per 128 x 256 block
+    of the 3-bit block kernel; the planner only takes splits that fit).  64 MiB replaces the reference's blocks*threads*2048-byte
     formula (537 MB for 256 CUs)."""
     return torch.zeros(64 * 1024 * 1024, dtype=torch.uint8, device=device)
 

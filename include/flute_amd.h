@@ -73,17 +73,24 @@ typedef struct flute_plan {
                             64-row blocks x splitk K slices - m_block 5 / 12; 128-row blocks x 2 / 4 slices meet inside the launch (splitk_mode 1), the others through fp32 slabs + the reduce pass), 5 = skinny MFMA kernel
                             (qgemm_skinny.h: 4-bit, 3 <= M <= 16, K = 32 x ring_depth x waves, layers whose 64-column
                             slabs fill 55..100 % of the CUs; weights and activations straight to registers),
-                            6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, m_tiles x 16 rows (128 or 64) x 128 columns
-                            output tiles x splitk K slices, one workgroup of 8 compute + 4 loader waves each, partial tiles
-                            combined inside the launch; automatic from M = 33 (4 bits) / 65 (2 bits) where its modelled time
-                            is 8 % under the other MFMA kernels' and one round of workgroups covers the output) */
+                            6 = split-K block kernel (qgemm_splitk.h: 2- / 4-bit, m_tiles x 16 rows (128 or 64) x 256 / kw columns
+                            (128; 64 with kw = 4 K parts per workgroup, 64-row tiles only - round 6) output tiles x splitk K slices,
+                            one workgroup of 8 compute + 4 loader waves each, partial tiles combined inside the launch; automatic
+                            from M = 33 (4 bits) / 65 (2 bits) where its modelled time is 8 % under the other MFMA kernels' (64-column
+                            tiles that fill half the chip: under the per-wave kernel's time + 4 us) and one round of workgroups
+                            covers the output),
+                            7 = lean MFMA decode kernel (qgemm_fastm.h, round 5: 4 bits, 5 <= M <= 16, K in {2048, 4096}, a
+                            workgroup = 4 unit rows x all of K, N / 16 workgroups of 8 waves between half a round and one
+                            round of the CUs, 32 KB + 32 copies x 4 KB of LDS = 160 KB; what it cannot take falls back) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit); family 3: block shape
-                            (4 / 5: 256- / 128-row blocks; 8 + rt: 3-bit blocks of rt = 1, 2, 4 row tiles) */
+                            (4 / 5: 256- / 128-row blocks; 8 + rt: 3-bit blocks of rt = 1, 2, 4 row tiles); family 6: row tiles of a
+                            column tile that run as consecutive blocks of ONE XCD when K is not split (1 = natural order, 2, 4, 8);
+                            family 7: 16 */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4); family 6: row tiles per output tile (8 / 4) */
     int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
     int waves;           /* waves per workgroup (decode: any count up to 16, not only powers of two) */
-    int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split) */
-    int splitk;          /* grid-level K split (fp32 slabs in workspace + reduce pass) */
+    int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split); family 6: K parts per workgroup (2 / 4) */
+    int splitk;          /* grid-level K split (fp32 slabs in the workspace; see splitk_mode) */
     int k_per_split;
     int lut_copies;
     unsigned grid, block;
@@ -108,10 +115,13 @@ typedef struct flute_plan {
  * NULL pointer) = automatic.  Plain data passed with the call: there is no process-global tuning state.
  *   family          5 skinny MFMA kernel (4-bit, M <= 16; waves 4 / 8 picks the in-workgroup K split);
  *                   6 split-K block kernel (splitk picks the K slices per tile; 1 = none; m_tiles 8 / 4: 128- / 64-row
- *                   tiles; waves 8 = without the four loader waves);
+ *                   tiles; kw 2 / 4: K parts per workgroup = 128- / 64-column tiles (4 with 64-row tiles only); m_block 1 / 2 / 4 / 8:
+ *                   row tiles per XCD group of the block order; waves must be 12 or automatic - the variant without loader
+ *                   waves was dropped in round 6);
+ *                   7 lean MFMA decode kernel (4 bits, 5 <= M <= 16, K in {2048, 4096}; falls back where it does not apply);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 1 / 2 per-wave MFMA
- *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 6 are rejected
+ *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 7 are rejected
  *                   (FLUTE_ERR_SHAPE).  m_tiles / waves / kw / splitk / slabs_per_wave given WITHOUT family = 6 belong to the
  *                   per-wave kernel: such a call never takes the split-K block kernel automatically
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)

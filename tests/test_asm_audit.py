@@ -78,4 +78,13 @@ def test_audit_rules_on_synthetic_streams(tmp_path):
     blk = "".join(f"\tv_dot2_f32_bf16 v{10 + i}, v{2 + i // 2}, v{6 + i % 2}, 0\n" for i in range(8)) + \
           "".join(f"\tv_cvt_pk_bf16_f32 v{20 + i}, v{10 + 2 * i}, v{11 + 2 * i}\n" for i in range(4))
     assert _audit_text(tmp_path, blk) == []
+    # round 6: a lane swap that reads a VGPR written by a VALU instruction less than two wait states earlier (hipcc pads its own
+    # swaps, not those inside asm statements) is flagged; with s_nop 1 (or two instructions) in between it is not
+    wr = "\tv_add_f32_e32 v10, v2, v3\n"
+    assert len(_audit_text(tmp_path, wr + "\tv_permlane16_swap_b32 v10, v11\n")) == 1
+    assert len(_audit_text(tmp_path, wr + "\tv_mov_b32_e32 v30, v1\n\tv_permlane32_swap_b32 v11, v10\n")) == 1
+    assert _audit_text(tmp_path, wr + "\ts_nop 1\n\tv_permlane16_swap_b32 v10, v11\n") == []
+    assert _audit_text(tmp_path, wr + "\tv_mov_b32_e32 v30, v1\n\tv_mov_b32_e32 v31, v1\n\tv_permlane16_swap_b32 v10, v11\n") == []
+    assert len(_audit_text(tmp_path, wr + "\ts_nop 1\n\tv_permlane16_swap_b32 v10, v11\n\tv_permlane16_swap_b32 v11, v12\n")) == 1   # back-to-back swaps sharing a register
+    assert _audit_text(tmp_path, wr + "\ts_nop 1\n\tv_permlane16_swap_b32 v10, v11\n\tv_permlane16_swap_b32 v12, v13\n") == []
 

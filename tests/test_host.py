@@ -215,3 +215,27 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert p2.returncode != 0 and "WORLD_SIZE=2" in (p2.stderr + p2.stdout)
+
+
+def test_every_key_of_the_shipped_table_resolves_to_a_legal_plan():
+    """flute_amd/data/gfx950_tuned.json is what the product serves (FluteLinear, tune_and_pack, bench.py): every key's template id
+    exists for its bit width, honours the key's TileP constraint, passes is_template_supported and gives flute_qgemm_plan a legal
+    plan for the key's shape at the bucket's batch size (the reference's tuner checks every id it stores: tune.py:294-392)."""
+    from flute_amd import _lib
+    table = tune.load_tuned_table()
+    assert len(table) > 5000
+    lib = _lib.get()
+    dt = {"float16": (0, torch.float16), "bfloat16": (1, torch.bfloat16)}
+    fams = {}
+    for key, tid in table.items():
+        mb, N, K, bits, g, sms, dtype, tile_p = key.split("|")
+        mb, N, K, bits, g, sms, tile_p = int(mb), int(N), int(K), int(bits), int(g), int(sms), int(tile_p)
+        cfg = flute_amd.TEMPLATE_CONFIGS.get((bits, tid))
+        assert cfg is not None, key
+        assert tile_p == 0 or cfg["TileP"] == tile_p, key
+        assert utils.is_template_supported(mb, N, K, bits, tid, sms, g, dt[dtype][1]), key
+        p = _lib.Plan()
+        assert lib.flute_qgemm_plan(dt[dtype][0], bits, g, mb, N, K, tid, sms, 64 << 20, p) == 0, key
+        assert p.grid >= 1 and p.block in (64 * w for w in range(1, 17)) and p.lds_bytes <= 160 * 1024 and p.workspace_needed <= 64 << 20, key
+        fams[p.family] = fams.get(p.family, 0) + 1
+    assert set(fams) >= {0, 2, 3, 5, 6, 7}, fams                   # the table reaches every kernel family

@@ -90,9 +90,22 @@ def rel(out, ref):
     return ((out - ref).norm() / ref.norm()).item()
 
 
-def check_shape_case(e, N, K, bits, g, dtype, uniform, Ms, seed, tile_p=32):
+def served_template(e, M, N, K, bits, g, dtype, tile_p):
+    """The template id the PRODUCT serves for this call - the shipped table's entry for the (shape, M bucket), as
+    FluteLinear / tune_and_pack / bench.py take it (flute_amd/data/gfx950_tuned.json, ~9.5 k keys: ids 28, 12, 5, 29, 24, 20, 18, ...)
+    - when it exists and shares the packed matrix's TileP; else the first id of that TileP (the automatic plan)."""
+    from flute_amd import tune
+    tid = tune.lookup_tuned(M, N, K, bits, g, e.num_sms, dtype, 32 if tile_p == 32 else None)
+    if tid is not None and e.fa.TEMPLATE_CONFIGS[(bits, tid)]["TileP"] == tile_p and \
+            e.utils.is_template_supported(M, N, K, bits, tid, e.num_sms, g, dtype):
+        return tid
+    return first_template(e.fa, bits, tile_p)
+
+
+def check_shape_case(e, N, K, bits, g, dtype, uniform, Ms, seed, tile_p=32, tuned=False):
     """tests/kernel.py::test_integer for one (shape, config): identity -> one-hot rows bit-exact, random rows
-    within tolerance, evaluated against the reference formula in fp32 on the GPU."""
+    within tolerance, evaluated against the reference formula in fp32 on the GPU.  tuned: every batch size runs the
+    template id of the shipped table (tune.py:294-392 checks the id it has just tuned), not the first id."""
     d = e.dev
     if not packable(N, bits, tile_p) or K % g:
         pytest.skip(f"N={N} K={K} not packable for b={bits} g={g}")
@@ -101,8 +114,9 @@ def check_shape_case(e, N, K, bits, g, dtype, uniform, Ms, seed, tile_p=32):
     S = torch.randn(N, K // g, device=d).to(dtype)
     table = (torch.arange(2 ** bits, device=d) if uniform else torch.randn(2 ** bits, device=d)).to(dtype)
     table2 = e.utils.make_qmap2_from_qmap(table)
-    tid = first_template(e.fa, bits, tile_p)
-    Q = e.utils.pack(W, bits, [tid], e.num_sms)
+    tid0 = first_template(e.fa, bits, tile_p)
+    tid_of = (lambda M: served_template(e, M, N, K, bits, g, dtype, tile_p)) if tuned else (lambda M: tid0)
+    Q = e.utils.pack(W, bits, [tid0], e.num_sms)                                # (the layout depends on TileP only)
     Sx = torch.repeat_interleave(S, g, dim=1).T                                 # [K, N]
     # identity input, sampled: 64 one-hot rows (first, last, random k) reproduce round_T(table*S) exactly
     ks = torch.randint(0, K, (64,), device=d)
@@ -111,17 +125,17 @@ def check_shape_case(e, N, K, bits, g, dtype, uniform, Ms, seed, tile_p=32):
     E[torch.arange(64), ks] = 1
     What_rows = table[W[ks].long()] * Sx[ks]
     for M in sorted(set(min(m, 64) for m in Ms)):
-        out = e.fa.qgemm(E[:M], Q, S, table, table2, e.ws, bits, g, tid, e.num_sms)
-        assert torch.equal(out, What_rows[:M]), ("one-hot", N, K, bits, g, dtype, M)
+        out = e.fa.qgemm(E[:M], Q, S, table, table2, e.ws, bits, g, tid_of(M), e.num_sms)
+        assert torch.equal(out, What_rows[:M]), ("one-hot", N, K, bits, g, dtype, M, tid_of(M))
     del E
     What = (table[W.long()] * Sx).float()                                        # [K, N] checker, fp32 copy
     del W, Sx
     for M in Ms:
         X = (torch.randn(M, K, device=d) / 100).to(dtype)
-        out = e.fa.qgemm(X, Q, S, table, table2, e.ws, bits, g, tid, e.num_sms)
+        out = e.fa.qgemm(X, Q, S, table, table2, e.ws, bits, g, tid_of(M), e.num_sms)
         ref = X.float() @ What
         err = ((out.float() - ref).norm() / ref.norm()).item()
-        assert err < tol_of(dtype), (N, K, bits, g, dtype, uniform, M, err)
+        assert err < tol_of(dtype), (N, K, bits, g, dtype, uniform, M, tid_of(M), err)
     del What
     torch.cuda.empty_cache()
 
@@ -131,7 +145,8 @@ def check_shape_case(e, N, K, bits, g, dtype, uniform, Ms, seed, tile_p=32):
 def test_supported_shapes_sweep(env, idx, slot):
     N, K = SUPPORTED_SHAPES[idx]
     bits, g, dtype, uniform, tile_p = COMBOS[(idx * PER_SHAPE + slot) % len(COMBOS)]
-    check_shape_case(env, N, K, bits, g, dtype, uniform, SWEEP_MS, seed=idx * 64 + slot, tile_p=tile_p)
+    # odd slots run the ids the product serves (the shipped table's entry per batch size), even slots the first id
+    check_shape_case(env, N, K, bits, g, dtype, uniform, SWEEP_MS, seed=idx * 64 + slot, tile_p=tile_p, tuned=bool(slot & 1))
 
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096)])

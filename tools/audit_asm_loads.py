@@ -150,6 +150,10 @@ def _dot_hazard(recent, text, used_srcs):
     return bad
 
 
+SWAP = re.compile(r"^v_permlane(16|32)_swap_b32\s+(v\d+)\s*,\s*(v\d+)")
+VALU_DST = re.compile(r"^v_\w+\s+(v\d+|v\[\d+:\d+\])\s*,")
+
+
 def audit(path):
     findings = []
     all_lines = open(path).read().split("\n")
@@ -158,6 +162,7 @@ def audit(path):
     vm_fifo = []          # hidden VMEM loads in flight: (line number, set of VGPRs)
     ds_set = []           # hidden LDS loads in flight
     dots = []             # [wait states since issue, dst regs] of recent v_dot* instructions
+    valu = []             # [wait states since issue, dst regs] of the last VALU writes (the lane-swap rule)
     for ln, raw in enumerate(open(path), 1):
         line = raw.split(";")[0].rstrip() if not raw.lstrip().startswith(";;#") else raw.strip()
         if raw.lstrip().startswith(";;#ASMSTART"):
@@ -206,6 +211,30 @@ def audit(path):
             if md:
                 dots.append([0, regs_of(md.group(2))])
             dots = [d for d in dots if d[0] < 3]
+        # ---- a lane swap reading a VGPR a VALU instruction wrote less than two wait states earlier (LLVM's gfx950 rule "VALU write
+        # vdst -> v_permlane*_swap read": hipcc pads its own swaps with s_nop 1, not those inside asm statements) ----
+        if text.startswith("s_nop"):
+            mm = re.match(r"s_nop\s+(\d+)", text)
+            for w in valu:
+                w[0] += int(mm.group(1)) + 1 if mm else 1
+        elif not text.startswith((".", ";")):
+            ms = SWAP.match(text)
+            if ms:
+                ops = regs_of(ms.group(2)) | regs_of(ms.group(3))
+                early = set()
+                for age, dst in valu:
+                    if age < 2:
+                        early |= ops & dst
+                if early:
+                    findings.append((kernel, ln, text + "   [lane swap reads a VALU result within 2 wait states]", sorted(early)))
+            for w in valu:
+                w[0] += 1
+            mw = VALU_DST.match(text)
+            if mw and not text.startswith("v_cmp"):
+                valu.append([0, regs_of(mw.group(1))])
+            if ms:                                            # (the swap writes both operands)
+                valu.append([0, regs_of(ms.group(2)) | regs_of(ms.group(3))])
+            valu = [w for w in valu if w[0] < 2]
         if text.startswith("s_waitcnt"):
             continue
         used = regs_of(text)
