@@ -281,17 +281,22 @@ int plan_fast(int bits, int lg, int M, int N, int K, int num_sms, int rank, int 
 
 // Lean MFMA decode kernel (qgemm_fastm.h, round 5): 4 bits, M <= 16, K = 4096 (8 waves x 512 k) or 2048 (8 x 256 k), a workgroup =
 // 4 unit rows (16 columns) x all of K; every wave's K range must hold >= 2 groups (its scale words are read as whole dwords).
-int plan_fastm(int bits, int lg, int M, int N, int K, flute_plan* p, OneArgs* oa) {
+// Round 6: ng column groups (4 unit rows each) per workgroup share one staged activation set: the smallest of 1, 2, 3 that covers the
+// layer in one round of workgroups (override slabs_per_wave = 1 / 2 / 3 fixes it).
+int plan_fastm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, flute_plan* p, OneArgs* oa) {
     if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 8 || (K != 4096 && K != 2048)) return FLUTE_ERR_SHAPE;
     const int W = 8, nm = K / (128 * W);
     if (((128 * nm) >> lg) < 2) return FLUTE_ERR_SHAPE;
     const int units = N / 4;
     if (units % 4) return FLUTE_ERR_SHAPE;
+    int ng = 1;
+    while (ng < 3 && ceil_div(units / 4, ng) > num_sms) ++ng;
+    if (ng_ovr >= 1 && ng_ovr <= 3) ng = ng_ovr;
     if (((size_t)N * (size_t)(K >> lg)) * 2 >= (size_t)0xfffffff0u || (size_t)units * K * 2 >= ((size_t)1 << 40)) return FLUTE_ERR_SHAPE;
     memset(p, 0, sizeof(*p));
     p->family = kFamilyFastM;
-    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = 1; p->waves = W; p->kw = W; p->splitk = 1; p->k_per_split = K;
-    p->grid = (unsigned)(units / 4); p->block = (unsigned)(W * 64);
+    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = ng; p->waves = W; p->kw = W; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)ceil_div(units / 4, ng); p->block = (unsigned)(W * 64);
     p->lds_bytes = fastm_lds_bytes(K); p->lut_copies = 32;
     p->ring_depth = nm; p->visits = 1; p->k_chunks = 1; p->one_shot = 0;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = nm; }
@@ -636,11 +641,17 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // 5.7 / 5.7 / 5.8 -> 4.3 / 4.3 / 4.5, 2048 x 4096 7.6 / 7.6 / 7.7 -> 5.4 / 5.4 / 5.6; not taken: more than one round (8192 x 4096:
     // 10.2 .. 10.8 against the skinny kernel's 8.9 .. 9.6: every workgroup pulls all of X through its CU), M <= 4 (the dot-product
     // lean kernel: 5.05 against 5.9)
+    // Round 6: two / three column groups per workgroup on ONE staged activation set make wider layers one round of workgroups
+    // (profiles/r06/call18_fastm_column_groups.log, M = 16, us, table's plan -> this): 8192 x 4096 10.1 -> 8.9 (2 groups, 256 workgroups),
+    // 11008 12.6 -> 11.4 (3 groups, 230), 6144 9.4 -> 8.4, 5120 9.2 -> 8.0, 8192 x 2048 6.9 -> 6.2; M = 8 on 11008 11.6 -> 11.0; not taken:
+    // more than one round even at three groups (14336: 16.0 against 13.1; 28672: 30 against 23)
+    const long fm_groups = N / 16;
+    const long fm_wgs = fm_groups <= (long)num_sms ? fm_groups : (fm_groups <= 2L * num_sms ? (fm_groups + 1) / 2 : (fm_groups + 2) / 3);
     const bool fastm_auto = ov.family < 0 && bits == 4 && M >= 5 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 &&
-                            (K == 4096 || K == 2048) && (long)(N / 16) <= (long)num_sms && (long)(N / 16) * 2 >= (long)num_sms &&
+                            (K == 4096 || K == 2048) && fm_wgs <= (long)num_sms && fm_wgs * 2 >= (long)num_sms &&
                             ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0;
     if (ov.family == kFamilyFastM || fastm_auto) {
-        if (plan_fastm(bits, lg, M, N, K, p, oa) == FLUTE_OK) return FLUTE_OK;
+        if (plan_fastm(bits, lg, M, N, K, num_sms, ov.family == kFamilyFastM ? ov.slabs : -1, p, oa) == FLUTE_OK) return FLUTE_OK;
         memset(p, 0, sizeof(*p));
     }
     {
@@ -1262,7 +1273,7 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
 
     if (p.family == kFamilyFastM) {
-        FastMKernel fn = fastm_kernel_b4(dtype, t.tile_p, p.waves, p.ring_depth, oa.lg);
+        FastMKernel fn = fastm_kernel_b4(dtype, t.tile_p, p.waves, p.ring_depth, oa.lg, p.slabs_per_wave);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);

@@ -25,7 +25,7 @@ typedef void (*FastKernel)(const uint32_t*, const void*, const void*, const uint
 FastKernel fast_kernel_b4(int dtype, int tile_p, int waves, int kw, int depth, int mb);
 // lean MFMA decode kernel (qgemm_fastm.h): 4 bits, M <= 16, a workgroup = 4 unit rows x all of K = 128 * nm * waves; lg = log2(group size)
 typedef void (*FastMKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
-FastMKernel fastm_kernel_b4(int dtype, int tile_p, int waves, int nm, int lg);
+FastMKernel fastm_kernel_b4(int dtype, int tile_p, int waves, int nm, int lg, int ng);   // ng: column groups (4 unit rows each) per workgroup, 1 .. 3
 // persistent one-shot decode kernel (qgemm_persist.h): mb rows per pass (1/2), depth = pieces per segment, nsets = register sets
 typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
 PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int nsets, int had);

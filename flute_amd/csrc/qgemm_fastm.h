@@ -37,8 +37,13 @@
 // Arithmetic contract: as the decode kernels (include/flute_amd.h): fp32 group scale on the group's partial sum.
 // Reference: qgemm_device's main loop for small M (flute/csrc/qgemm_kernel.hpp:617-712), Stream-K fix-up replaced by the
 // in-workgroup K split (tile_scheduler_utils.hpp:58-211).
-// Host contract (api.hip: plan_fastm): num_bits = 4, M <= 16, K == 128 * NM * W, units = N / 4 a multiple of 4, group size
-// 2^LG in {64, 128, 256}, LDS = 32 KB + 32 K bytes <= 160 KB (K <= 4096).
+// Round 6 - NG column groups per workgroup (1, 2, 3): the workgroup owns 4 NG unit rows and multiplies NG weight tiles against ONE
+// staged activation set - a step's fragment read feeds NG MFMAs, the 128 KB of activations cross the CU's texture addresser once
+// for NG x the work.  11008-, 8192- and 6144-wide layers become ONE round of workgroups (230 / 256 / 192) where the NG = 1 form
+// needed 2.7 / 2 / 1.5 and lost to the skinny kernel (8192 x 4096: 10.2 against 8.9 us).
+// Host contract (api.hip: plan_fastm): num_bits = 4, M <= 16, K == 128 * NM * W, units = N / 4 a multiple of 4 (the last workgroup
+// may hold fewer than NG groups: its missing unit rows read as zero and store nothing), group size 2^LG in {64, 128, 256},
+// LDS = 32 KB + 32 K bytes <= 160 KB (K <= 4096).
 #pragma once
 #include "qgemm_oneshot.h"
 #include "mfma.h"
@@ -47,7 +52,7 @@ namespace flute_amd {
 
 __host__ __device__ constexpr size_t fastm_lds_bytes(int K) { return (size_t)32768 + (size_t)K * 32; }
 
-template <typename T, int TILEP, int W, int NM, int LG>
+template <typename T, int TILEP, int W, int NM, int LG, int NG = 1>
 __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int M, uint64_t* __restrict__ stamps) {
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     static_assert(NM >= 1 && NM <= 4, "macro-steps per wave");
     static_assert(NGW >= 1 && NGW <= 8 && SPG * NGW == 4 * NM, "group runs of whole steps");
     static_assert(32768 + K * 32 <= 160 * 1024, "activations beside the table image");
+    static_assert(NG >= 1 && NG <= 3, "column groups per workgroup (a step's 4 NG lookups + 1 fragment read are counted by ONE lgkmcnt)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (lds_base_of(smem) != 0) __builtin_trap();                  // absolute LDS addresses
@@ -89,27 +95,34 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     const int kg = lane >> 4;                                       // k-chunk of a 32-k step; also: unit of the lane's outputs
     const int ju = lane & 3;                                        // byte of the packed word = column of the unit
     const int uu = i16 >> 2;                                        // unit of the workgroup
-    const int unit0 = blockIdx.x * 4;
+    const int unit0 = blockIdx.x * (4 * NG);
+    const int nunits = N >> 2;
 
     // ---- requests, oldest first: table word, weights, scale words, activations ----
     const srd_t lut_srd = make_srd(QM2, 1024u);
     uint32_t lut_v = buf_load4((uint32_t)(wave * ENT + (lane & (ENT - 1))) * 4u, lut_srd);
 
-    const srd_t q_srd = make_srd(Qp + (size_t)unit0 * (K / 2), 4u * (uint32_t)K * 2u);
-    ring16_t q[NM];
-    static_for<NM>([&](auto t_tag) {
-        constexpr int t = decltype(t_tag)::value;
-        const uint32_t vo = (uint32_t)uu * (uint32_t)(K * 2) + (uint32_t)(wave * KWV + t * 128 + ju * 32 + kg * 8) * 2u;
-        q[t] = buf_load16_nt(vo, q_srd, 0);
+    // (unit rows past the layer's last - the last workgroup of a layer whose groups NG does not divide - lie past the descriptor: zero)
+    const srd_t q_srd = make_srd(Qp + (size_t)unit0 * (K / 2), (uint32_t)min(4 * NG, nunits - unit0) * (uint32_t)K * 2u);
+    ring16_t q[NG][NM];
+    static_for<NG>([&](auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        static_for<NM>([&](auto t_tag) {
+            constexpr int t = decltype(t_tag)::value;
+            const uint32_t vo = (uint32_t)(4 * g + uu) * (uint32_t)(K * 2) + (uint32_t)(wave * KWV + t * 128 + ju * 32 + kg * 8) * 2u;
+            q[g][t] = buf_load16_nt(vo, q_srd, 0);
+        });
     });
     // scale words of the lane's OUTPUT columns: unit kg, columns r = 0..3, the 8 group slots from the wave's first group
     const srd_t s_srd = make_srd(Sp, (uint32_t)((size_t)N << (lG + 1)));
-    ring16_t sc[4];
-    {
-        const int unit = unit0 + kg;
+    ring16_t sc[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int unit = unit0 + 4 * g + kg;
         const int col0 = (unit / TILEP) * (4 * TILEP) + (unit % TILEP);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[r] = buf_load16((uint32_t)((((col0 + r * TILEP) << lG) + wave * NGW) * 2), s_srd, 0);
+        for (int r = 0; r < 4; ++r)      // (a unit past the layer: its columns lie past S - zero)
+            sc[g][r] = buf_load16(unit < nunits ? (uint32_t)((((col0 + r * TILEP) << lG) + wave * NGW) * 2) : 0xfffffff0u, s_srd, 0);
     }
     // activations: request (t, r) = rows 4 r .. 4 r + 3 x the 16 chunks of macro-step t; rows >= M lie past the descriptor's
     // range (zero).  Lane l: row 4 r + l / 16, chunk l % 16.
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     FLUTE_MSTAMP(2);
 
     // ---- table image: entry e at [128 e, 128 e + 128): a wave writes RUNS runs of 8 entries (1 KiB, lane-linear) ----
-    vm_wait_regs<NM + 4 + XA * XQ>(lut_v);
+    vm_wait_regs<NG * (NM + 4) + XA * XQ>(lut_v);
     FLUTE_MSTAMP(3);
     {
         uint32_t te[RUNS];
@@ -155,9 +168,13 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     stage_x(std::integral_constant<int, 0>{}, std::integral_constant<int, (XA - 1) * XQ>{});
     FLUTE_MSTAMP(6);
     // the weights and scale words are older than the activations just waited for: all returned
-    static_for<NM>([&](auto t_tag) { ring16_t& r = q[decltype(t_tag)::value]; asm volatile("" : "+v"(r) : : "memory"); });
+    static_for<NG>([&](auto g_tag) {
+        static_for<NM>([&](auto t_tag) { ring16_t& r = q[decltype(g_tag)::value][decltype(t_tag)::value]; asm volatile("" : "+v"(r) : : "memory"); });
+    });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { ring16_t& sreg = sc[r]; asm volatile("" : "+v"(sreg) : : "memory"); }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ring16_t& sreg = sc[g][r]; asm volatile("" : "+v"(sreg) : : "memory"); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // the table image is complete
     FLUTE_MSTAMP(7);
@@ -169,32 +186,45 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     // activation fragment of step (t, s): chunk 16 t + 4 s + kg of the wave's range, slot i16 ^ (4 (s % 2) + kg)
     const uint32_t xa_e = xreg + (uint32_t)kg * 256u + (uint32_t)((i16 ^ kg) * 16);
     const uint32_t xa_o = xreg + (uint32_t)(4 + kg) * 256u + (uint32_t)((i16 ^ (4 + kg)) * 16);
-    uint32_t v[2][4];
+    uint32_t v[2][NG][4];
     ring16_t xb[2];
     auto issue_step = [&](auto n_tag) {
         constexpr int n = decltype(n_tag)::value;
         constexpr int t = n / 4, s = n % 4;
-        uint32_t ad[4];
+        static_for<NG>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            uint32_t ad[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t wsrc = (uint32_t)__builtin_amdgcn_mov_dpp((int)q[t][c], s * 0x55, 0xF, 0xF, true);       // quad_perm [s, s, s, s]
-            ad[c] = __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
-        }
-        asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]));
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t wsrc = (uint32_t)__builtin_amdgcn_mov_dpp((int)q[g][t][c], s * 0x55, 0xF, 0xF, true);       // quad_perm [s, s, s, s]
+                ad[c] = __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
+            }
+            asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[n & 1][c] = lds_lookup32(ad[c]);
+            for (int c = 0; c < 4; ++c) v[n & 1][g][c] = lds_lookup32(ad[c]);
+        });
         ring16_t& dst = xb[n & 1];
         const uint32_t xa = (s & 1) ? xa_o : xa_e;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(xa), "n"(t * 4096 + (s >> 1) * 2048) : "memory");
     };
     auto wait_step = [&](auto n_tag, auto younger_tag) {
         constexpr int n = decltype(n_tag)::value;
-        uint32_t (&vv)[4] = v[n & 1];
+        uint32_t (&vv)[NG][4] = v[n & 1];
         ring16_t& xx = xb[n & 1];
-        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(xx) : "n"(decltype(younger_tag)::value) : "memory");
+        constexpr int Y = decltype(younger_tag)::value;
+        if constexpr (NG == 1)
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(vv[0][0]), "+v"(vv[0][1]), "+v"(vv[0][2]), "+v"(vv[0][3]), "+v"(xx) : "n"(Y) : "memory");
+        else if constexpr (NG == 2)
+            asm volatile("s_waitcnt lgkmcnt(%9)" : "+v"(vv[0][0]), "+v"(vv[0][1]), "+v"(vv[0][2]), "+v"(vv[0][3]),
+                         "+v"(vv[1][0]), "+v"(vv[1][1]), "+v"(vv[1][2]), "+v"(vv[1][3]), "+v"(xx) : "n"(Y) : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(%13)" : "+v"(vv[0][0]), "+v"(vv[0][1]), "+v"(vv[0][2]), "+v"(vv[0][3]),
+                         "+v"(vv[1][0]), "+v"(vv[1][1]), "+v"(vv[1][2]), "+v"(vv[1][3]),
+                         "+v"(vv[2 % NG][0]), "+v"(vv[2 % NG][1]), "+v"(vv[2 % NG][2]), "+v"(vv[2 % NG][3]), "+v"(xx) : "n"(Y) : "memory");
     };
-    f32x4_t accf = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t part = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t accf[NG], part[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { accf[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; part[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     issue_step(std::integral_constant<int, 0>{});
     static_for<4 * NM>([&](auto n_tag) {
         constexpr int n = decltype(n_tag)::value;
@@ -202,17 +232,20 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
         // the next step's reads first - unless it opens a macro-step whose activations are not in LDS yet (written below)
         if constexpr (n + 1 < 4 * NM && s != 3) issue_step(std::integral_constant<int, n + 1>{});
         if constexpr (t + 2 < NM) request_x(std::integral_constant<int, t + 2>{}, std::integral_constant<int, s>{});
-        wait_step(n_tag, std::integral_constant<int, (n + 1 < 4 * NM && s != 3) ? 5 : 0>{});
-        const u32x4_t a = {v[n & 1][0], v[n & 1][1], v[n & 1][2], v[n & 1][3]};
+        wait_step(n_tag, std::integral_constant<int, (n + 1 < 4 * NM && s != 3) ? 4 * NG + 1 : 0>{});
         const u32x4_t b = {xb[n & 1][0], xb[n & 1][1], xb[n & 1][2], xb[n & 1][3]};
-        if constexpr (n % SPG == 0) part = Mfma<T>::run(a, b, f32x4_t{0.f, 0.f, 0.f, 0.f});
-        else part = Mfma<T>::run(a, b, part);
-        if constexpr (n % SPG == SPG - 1) {
-            constexpr int gi = n / SPG;                             // group slot of the wave's range
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t w = sc[r][gi / 2];
-                accf[r] = __builtin_fmaf(part[r], scale_to_float<T>((gi & 1) ? (w >> 16) : (w & 0xffffu)), accf[r]);
+        for (int g = 0; g < NG; ++g) {
+            const u32x4_t a = {v[n & 1][g][0], v[n & 1][g][1], v[n & 1][g][2], v[n & 1][g][3]};
+            if constexpr (n % SPG == 0) part[g] = Mfma<T>::run(a, b, f32x4_t{0.f, 0.f, 0.f, 0.f});
+            else part[g] = Mfma<T>::run(a, b, part[g]);
+            if constexpr (n % SPG == SPG - 1) {
+                constexpr int gi = n / SPG;                         // group slot of the wave's range
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t w = sc[g][r][gi / 2];
+                    accf[g][r] = __builtin_fmaf(part[g][r], scale_to_float<T>((gi & 1) ? (w >> 16) : (w & 0xffffu)), accf[g][r]);
+                }
             }
         }
         if constexpr (s == 3 && t + 1 < NM) {
@@ -224,20 +257,26 @@ __global__ __launch_bounds__(W * 64) void qgemm_fastm_kernel(
     FLUTE_MSTAMP(9);
 
     // ---- K split: partial tiles -> the waves' own regions -> one barrier -> every wave sums 256 / W outputs ----
-    *reinterpret_cast<float4*>(smem + xreg + (uint32_t)lane * 16u) = make_float4(accf[0], accf[1], accf[2], accf[3]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        *reinterpret_cast<float4*>(smem + xreg + (uint32_t)g * 1024u + (uint32_t)lane * 16u) = make_float4(accf[g][0], accf[g][1], accf[g][2], accf[g][3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FLUTE_MSTAMP(10);
-    constexpr int OPW = 256 / W;                                    // outputs per wave
+    constexpr int OPW = 256 / W;                                    // outputs per wave and column group
     if (lane < OPW) {
         const int f = wave * OPW + lane;                            // float f of a partial tile: lane f / 4 of the MFMA layout, register f % 4
-        float sum = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) sum += __builtin_bit_cast(float, lds_ld32(X_BASE + (uint32_t)w2 * REGION + (uint32_t)f * 4u));
         const int ls = f >> 2, r = f & 3;
-        const int m = ls & 15, unit = unit0 + (ls >> 4);
-        const int col = (unit / TILEP) * (4 * TILEP) + (unit % TILEP) + r * TILEP;
-        if (m < M) reinterpret_cast<uint16_t*>(Dp)[(size_t)m * N + col] = NT::from_float(sum);
+        const int m = ls & 15;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) sum += __builtin_bit_cast(float, lds_ld32(X_BASE + (uint32_t)w2 * REGION + (uint32_t)g * 1024u + (uint32_t)f * 4u));
+            const int unit = unit0 + 4 * g + (ls >> 4);
+            const int col = (unit / TILEP) * (4 * TILEP) + (unit % TILEP) + r * TILEP;
+            if (m < M && unit < nunits) reinterpret_cast<uint16_t*>(Dp)[(size_t)m * N + col] = NT::from_float(sum);
+        }
     }
 #ifdef FLUTE_STAMPS
     FLUTE_MSTAMP(11);

@@ -226,9 +226,15 @@ def test_plan_families_and_invariants():
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 17, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 4
     assert lib.flute_qgemm_plan_ex(0, 4, 64, 1, 4096, 4096, 18, 256, 64 << 20, None, q) == 0 and q.one_shot >= 1 and q.ring_depth == 8
     # skinny MFMA kernel (family 5): 4-bit, 3 <= M <= 16, slabs of 64 columns filling 55..100 % of the CUs (or >= 1.7 rounds), K = 4096
-    rc, p = plan(16, 11008, 4096)
+    rc, p = plan(16, 11008, 4096, ovr=_lib.Overrides(family=5))
     assert rc == 0 and p.family == 5 and (p.grid, p.waves, p.kw, p.ring_depth, p.splitk, p.workspace_needed) == (172, 8, 8, 16, 1, 0)
     assert p.lds_bytes <= 160 * 1024
+    rc, p = plan(16, 11008, 4096)                            # round 6: the lean MFMA decode kernel, three column groups per workgroup on one staged activation set (11.4 against 12.6 us)
+    assert rc == 0 and p.family == 7 and (p.grid, p.slabs_per_wave, p.waves, p.block) == (230, 3, 8, 512)
+    rc, p = plan(16, 8192, 4096)
+    assert rc == 0 and p.family == 7 and (p.grid, p.slabs_per_wave) == (256, 2)
+    rc, p = plan(16, 14336, 4096)                            # 896 groups: more than one round even at three groups per workgroup - the skinny kernel
+    assert rc == 0 and p.family == 5 and p.grid == 224
     rc, p = plan(4, 14336, 4096)
     assert rc == 0 and p.family == 5 and p.grid == 224
     rc, p = plan(16, 28672, 4096)                            # 448 slabs: the per-wave kernel, two slabs per wave, no lane sharing
@@ -317,7 +323,9 @@ def test_plan_invariants_over_random_shapes():
                 assert p.workspace_needed == 0, what
         elif p.family == 7:                                       # lean MFMA decode kernel (qgemm_fastm.h's host contract)
             assert bits == 4 and 5 <= M <= 16 and K in (2048, 4096) and g >= 64 and (K // 8) // g >= 2 and tid % 4 == 0, what
-            assert p.grid == N // 16 and p.grid <= num_sms and p.waves == 8 and p.lds_bytes == 32768 + 32 * K and p.ring_depth * 128 * 8 == K, what
+            ng = p.slabs_per_wave                                  # column groups per workgroup (round 6): the fewest that make one round
+            assert ng in (1, 2, 3) and p.grid == -(-(N // 16) // ng) and p.grid <= num_sms and (ng == 1 or -(-(N // 16) // (ng - 1)) > num_sms), what
+            assert p.waves == 8 and p.lds_bytes == 32768 + 32 * K and p.ring_depth * 128 * 8 == K, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what

@@ -388,16 +388,17 @@ def test_lean_decode_kernel(env):
 def test_lean_mfma_decode_kernel(env):
     """The lean MFMA decode kernel (qgemm_fastm.h, round 5; family 7): a workgroup = 4 unit rows x all of K, its 8 waves
     split K, M <= 16.  Every instantiation (K = 4096 / 2048 x group size x dtype x TileP) x M in {1, 5, 8, 13, 16} against
-    the oracle, one-hot rows bit-exact (tests/kernel.py:30-36), an arbitrary pair codebook included."""
+    the oracle, one-hot rows bit-exact (tests/kernel.py:30-36), an arbitrary pair codebook included.  Round 6: one, two and three
+    column groups per workgroup on one staged activation set (slabs_per_wave), also where the last workgroup holds fewer groups
+    than the others (N = 11008: 688 groups, N = 5248: 328 groups, at three per workgroup)."""
     from flute_amd import dev
     d = env.dev
     cases = [
         # tile_p, g, dtype, K, N
         (32, 64, torch.float16, 4096, 1024), (64, 128, torch.bfloat16, 4096, 2048), (32, 256, torch.float16, 4096, 512),
         (64, 64, torch.bfloat16, 4096, 1024), (32, 64, torch.float16, 2048, 1024), (64, 128, torch.bfloat16, 2048, 2048),
-        (32, 128, torch.float16, 4096, 11008 // 128 * 128),
+        (32, 128, torch.float16, 4096, 11008 // 128 * 128), (32, 64, torch.bfloat16, 2048, 5248),
     ]
-    ovr = dev.Overrides(family=7)
     for (tile_p, g, dtype, K, N) in cases:
         bits = 4
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 79 + N % 13 + g)
@@ -409,19 +410,21 @@ def test_lean_mfma_decode_kernel(env):
                 grid = torch.randn(256, 2).to(dtype)
                 t2 = grid.view(16, 16, 2).contiguous().view(torch.float32)
             What = env.O.dequantize(Q.numpy(), S, t2, bits, g, tile_p).float()
-            for M in (1, 5, 8, 13, 16):
+            for M, ng in [(M, ng) for M in (1, 5, 8, 13, 16) for ng in ((1, 2, 3) if M in (5, 16) else (-1,))]:
+                ovr = dev.Overrides(family=7, slabs_per_wave=ng)
                 plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
-                assert plan["family"] == 7 and plan["grid"] == N // 16 and plan["waves"] == 8 and plan["lds_bytes"] == 32768 + 32 * K, plan
+                assert plan["family"] == 7 and plan["waves"] == 8 and plan["lds_bytes"] == 32768 + 32 * K, plan
+                assert plan["grid"] == -(-(N // 16) // plan["slabs_per_wave"]) and (ng < 0 or plan["slabs_per_wave"] == ng), plan
                 X = (torch.randn(M, K) / 100).to(dtype)
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert out.shape == (M, N)
-                assert rel_err(out, X.float() @ What) < tol_of(dtype), (tile_p, g, dtype, K, N, M, pair_codebook, rel_err(out, X.float() @ What))
+                assert rel_err(out, X.float() @ What) < tol_of(dtype), (tile_p, g, dtype, K, N, M, ng, pair_codebook, rel_err(out, X.float() @ What))
                 ks = torch.randint(0, K, (M,))
                 ks[0] = (0, K - 1)[M % 2]
                 E = torch.zeros(M, K, dtype=dtype)
                 E[torch.arange(M), ks] = 1
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
-                assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, pair_codebook)
+                assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, ng, pair_codebook)
     # not taken (the override falls back): 17 rows, 2 / 3 bits, 32-wide groups, other K, one group per wave
     for (M, K, bits, g) in ((17, 4096, 4, 64), (8, 4096, 2, 64), (8, 4096, 3, 64), (8, 4096, 4, 32), (8, 8192, 4, 64), (8, 2048, 4, 256)):
         plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=7))

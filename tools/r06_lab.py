@@ -34,3 +34,48 @@ elif case == "auto":      # the automatic plan against the forced alternatives o
         L.time_one(M, N, K, 4, f16, dict(family=2), tag="per-wave")
         L.time_one(M, N, K, 4, f16, dict(family=6, kw=4), tag="kp4 best")
         L.time_one(M, N, K, 4, f16, dict(family=6, kw=2), tag="kp2 best")
+elif case == "fastm":     # lean MFMA decode kernel with NG column groups per workgroup: check against fp32 + one-hot rows, then time
+    import json
+    from flute_amd import dev, utils
+    import flute_amd
+    d = L.d
+    nfail = 0
+    for (tile_p, g, dtype, K, N) in ((32, 64, f16, 4096, 4096), (32, 64, f16, 4096, 11008), (64, 128, bf16, 4096, 8192), (32, 256, f16, 4096, 5120),
+                                     (32, 64, bf16, 2048, 6144), (64, 64, f16, 2048, 1296 * 4), (32, 64, f16, 4096, 208)):
+        torch.manual_seed(K + N)
+        if N % (4 * tile_p):
+            continue
+        W = torch.randint(0, 16, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(16, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = L.tid_of(4, tile_p)
+        Q = utils.pack(W, 4, [tid], L.num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        for M in (5, 11, 16):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for ng in (1, 2, 3):
+                ovr = dev.Overrides(family=7, slabs_per_wave=ng)
+                pl = dev.get_plan(M, N, K, 4, g, tid, L.num_sms, dtype, ovr)
+                if pl["family"] != 7:
+                    continue
+                o = dev.qgemm_planned(X, Q, S, table, table2, L.ws, 4, g, tid, L.num_sms, ovr)
+                o1 = dev.qgemm_planned(E, Q, S, table, table2, L.ws, 4, g, tid, L.num_sms, ovr)
+                err = ((o.float() - ref).norm() / ref.norm()).item()
+                ok = err < (1e-3 if dtype == f16 else 4e-3) and bool(torch.equal(o1, What[ks]))
+                if not ok:
+                    nfail += 1
+                    print(json.dumps({"kind": "check_fastm", "N": N, "K": K, "g": g, "dtype": str(dtype), "M": M, "ng": ng, "grid": pl["grid"], "err": err,
+                                      "onehot": bool(torch.equal(o1, What[ks]))}), flush=True)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    print(json.dumps({"kind": "check_fastm_summary", "failed": nfail}), flush=True)
+    for (M, N, K) in ((16, 4096, 4096), (16, 11008, 4096), (16, 8192, 4096), (16, 6144, 4096), (16, 14336, 4096), (8, 11008, 4096), (16, 5120, 4096), (16, 8192, 2048),
+                      (16, 28672, 4096)):
+        L.time_one(M, N, K, 4, f16, None, steps=300, tag="tuned table")
+        for ng in (1, 2, 3):
+            L.time_one(M, N, K, 4, f16, dict(family=7, slabs_per_wave=ng), steps=300, tag=f"fastm ng={ng}")
