@@ -475,10 +475,14 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     // 172, 41.8 -> 40.3 on 256; the variant without them - override waves = 8 - was dropped in round 6)
     if (ov.waves > 0 && ov.waves != 12) return FLUTE_ERR_SHAPE;
     const int ldw = SK_LOADERS;
-    // m_block: row tiles of a column tile per XCD group (block order of launches without K slices); 2 since round 4, override 1 / 2 / 4 / 8
+    // m_block: row tiles of a column tile per XCD group (block order of launches without K slices); override 1 / 2 / 4 / 8
     {
         const int tm = ceil_div(M, best.rt * 16);
-        int E = (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4 || ov.m_block == 8) ? ov.m_block : 2;
+        // (round 6: as many of a column tile's row tiles as divide them, up to eight - M = 256 on 4096^2, four 64-row tiles: 16.4 / 15.9 / 15.6 us
+        // at 1 / 2 / 4 per group, profiles/r06/call20_*.log; M = 512 on 2048 x 4096: 16.4 / 16.3 / 16.1 / 16.1 at 1 / 2 / 4 / 8)
+        int E = 8;
+        while (E > 1 && (tm % E || ((tm / E) & (tm / E - 1)))) E >>= 1;
+        if (ov.m_block == 1 || ov.m_block == 2 || ov.m_block == 4 || ov.m_block == 8) E = ov.m_block;
         if (best.sk != 1 || tm % E || ((tm / E) & (tm / E - 1))) E = 1;
         p->m_block = E;
     }

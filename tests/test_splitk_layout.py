@@ -138,7 +138,7 @@ def test_plan_family6():
     assert rc == 0 and p.family == 6 and p.block == 768 and p.waves == 12 and p.kw == 4      # 8 compute + 4 loader waves; round 6: four K parts
     assert _plan(256, 4096, 4096, family=6, waves=8)[0] != 0                                 # the variant without loader waves was dropped in round 6
     assert p.m_tiles == 4 and p.splitk == 1 and p.k_per_split == 4096 and p.grid == 256 and p.splitk_mode == 0     # 64 x 64 tiles over all of K: no seam (15.5 us; 64 x 128 x two slices 18.3)
-    assert p.workspace_needed == 0 and p.lds_bytes == 32768 + 4 * 3 * 8192 + 2 * 4096 and p.m_block == 2
+    assert p.workspace_needed == 0 and p.lds_bytes == 32768 + 4 * 3 * 8192 + 2 * 4096 and p.m_block == 4      # all four row tiles of a column tile on one XCD
     rc, p = _plan(256, 4096, 4096, family=6, kw=2)
     assert rc == 0 and p.kw == 2 and p.m_tiles == 4 and p.splitk == 2 and p.k_per_split == 2048 and p.grid == 256 and p.splitk_mode == 1     # rounds 4 / 5: 64-row tiles x two slices
     assert p.workspace_needed == 2 * 128 * 32768 + (64 << 10) and p.lds_bytes == 32768 + 49152 + 16384   # 32 KB per 64-row tile and slice

@@ -79,3 +79,11 @@ elif case == "fastm":     # lean MFMA decode kernel with NG column groups per wo
         L.time_one(M, N, K, 4, f16, None, steps=300, tag="tuned table")
         for ng in (1, 2, 3):
             L.time_one(M, N, K, 4, f16, dict(family=7, slabs_per_wave=ng), steps=300, tag=f"fastm ng={ng}")
+elif case == "m256x":     # M = 256 on 4096^2 and its neighbours: XCD group size and request distance
+    for mb in (1, 2, 4):
+        L.time_one(256, 4096, 4096, 4, f16, dict(family=6, splitk=1, kw=4, m_block=mb), tag=f"{tag} xcd_group_{mb}")
+    L.time_one(256, 4096, 4096, 4, bf16, dict(family=6, splitk=1, kw=4), tag=tag)
+    L.time_one(128, 4096, 4096, 4, f16, dict(family=6, splitk=2, kw=4), tag=tag)
+    L.time_one(256, 11008, 4096, 4, f16, dict(family=6, splitk=1, kw=2, m_tiles=8), tag=tag)
+    L.time_one(1024, 4096, 4096, 4, f16, dict(family=6, splitk=1, kw=2, m_tiles=8), tag=tag)
+    L.time_one(256, 8192, 8192, 4, f16, dict(family=6, splitk=2, kw=2, m_tiles=8), tag=tag)
