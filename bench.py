@@ -159,14 +159,16 @@ def _timestamp(ts, slot):
         raise RuntimeError(f"flute_debug_timestamp: {rc}")
 
 
-def time_graph(layer, steps, warmup, sync, cold=True):
+def time_graph(layer, steps, warmup, sync, cold=True, replays=1):
     """Capture `steps` launches in one hipGraph, bracketed INSIDE the graph by two device-clock stamps (one-lane kernels
     writing the chip-wide 100 MHz clock: the first runs when everything before it has finished, the second when the last
     step has), replay once.  Returns (ms between the stamps, host wall ms around sync()).  HIP events around the same replay
     are recorded too (LAST_TIMING["events_ms"]): a graph launch bracketed by events carries a FIXED 16 - 19 us of launch /
     marker overhead per replay whatever it holds (profiles/r05/graph_replay_fixed_cost_probe.json: 97.6 us for 20 steps,
     183.0 for 40, 8190 for 2000 - slope 4.09 us per step at every length), i.e. +0.8 us per step at 20 steps and nothing
-    at 2000; the stamps see the launches themselves.  cold: flush the caches (untimed) before the timed replay."""
+    at 2000; the stamps see the launches themselves.  cold: flush the caches (untimed) before the timed replay.
+    replays > 1: that many timed replays of the same K steps, each behind its own flush and barrier; the MEDIAN replay is returned,
+    every replay's time is kept in LAST_TIMING (median + min)."""
     for i in range(warmup):
         layer.step(i)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -191,29 +193,33 @@ def time_graph(layer, steps, warmup, sync, cold=True):
     for _ in range(max(2, min(5000, int(30.0 / max(w0.elapsed_time(w1), 1e-3))))):
         graph.replay()
     torch.cuda.synchronize()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync()
-    t0 = time.perf_counter()
-    if cold:
-        flush_l3(dev)     # stream-ordered, in front of the start event
-    else:
-        graph.replay()                  # untimed spacer: the GPU stays busy while the host enqueues the timed replay
-    start.record()
-    graph.replay()
-    end.record()
-    torch.cuda.synchronize()
-    sync()
-    wall_ms = (time.perf_counter() - t0) * 1e3
-    ev_ms = start.elapsed_time(end)
-    t = ts.cpu()
-    dev_ms = float(int(t[1]) - int(t[0])) * 1e-5            # ticks of 10 ns
+    runs = []
+    for _ in range(max(1, replays)):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
+        t0 = time.perf_counter()
+        if cold:
+            flush_l3(dev)     # stream-ordered, in front of the start event
+        else:
+            graph.replay()                  # untimed spacer: the GPU stays busy while the host enqueues the timed replay
+        start.record()
+        graph.replay()
+        end.record()
+        torch.cuda.synchronize()
+        sync()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        ev_ms = start.elapsed_time(end)
+        t = ts.cpu()
+        dev_ms = float(int(t[1]) - int(t[0])) * 1e-5            # ticks of 10 ns
+        ok = 0.0 < dev_ms <= ev_ms * 1.001 + 0.01                # a stamp that did not run: fall back on the events, and say so
+        runs.append((dev_ms if ok else ev_ms, wall_ms, ev_ms, dev_ms, ok))
+    runs.sort(key=lambda r: r[0])
+    best, wall_ms, ev_ms, dev_ms, ok = runs[len(runs) // 2]      # the median replay
     LAST_TIMING.clear()
-    LAST_TIMING.update({"events_ms": ev_ms, "device_clock_ms": dev_ms})
-    if not (0.0 < dev_ms <= ev_ms * 1.001 + 0.01):           # a stamp that did not run: fall back on the events, and say so
-        LAST_TIMING["clock"] = "hip events (device stamps implausible)"
-        return ev_ms, wall_ms
-    LAST_TIMING["clock"] = "device clock stamps inside the graph"
-    return dev_ms, wall_ms
+    LAST_TIMING.update({"events_ms": ev_ms, "device_clock_ms": dev_ms, "replays_ms": [round(r[0], 6) for r in runs],
+                        "min_ms": runs[0][0], "median_ms": best})
+    LAST_TIMING["clock"] = "device clock stamps inside the graph" if ok else "hip events (device stamps implausible)"
+    return best, wall_ms
 
 
 def time_eager(layer, steps, warmup):
@@ -448,10 +454,10 @@ def main():
         tid = layer.template_id = args.template_id
     else:
         tid = layer.tune()
-    ev_ms, wall_ms = time_graph(layer, args.steps, args.warmup, sync)
+    ev_ms, wall_ms = time_graph(layer, args.steps, args.warmup, sync, replays=5)      # five timed replays of the K steps: the median is the line's figure
     headline_timing = dict(LAST_TIMING)
     eager_ms = time_eager(layer, min(args.steps, 500), 10)
-    t = torch.tensor([ev_ms, wall_ms, headline_timing["events_ms"]], device=device, dtype=torch.float64)
+    t = torch.tensor([ev_ms, wall_ms, headline_timing["events_ms"], headline_timing["min_ms"]], device=device, dtype=torch.float64)
     ranks_counted = 1
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,7 +465,7 @@ def main():
         dist.all_reduce(ones)                           # every rank adds 1 over RCCL: the rank count the line reports
         ranks_counted = int(ones.item())
         assert ranks_counted == args.gpus, (ranks_counted, args.gpus)
-    ev_ms, wall_ms, hip_events_ms = t.tolist()
+    ev_ms, wall_ms, hip_events_ms, min_ms = t.tolist()
     ms_per_step = ev_ms / args.steps
     bytes_step = layer.bytes()
     value = world * bytes_step / (ms_per_step * 1e-3) / 1e9
@@ -625,6 +631,8 @@ def main():
             "frac_of_pure_read_floor": None if floor_us is None else round(floor_us / (ms_per_step * 1e3), 4),
             "bytes_per_launch": bytes_step,
             "kernel_us": round(ms_per_step * 1e3, 3),
+            "kernel_us_min_of_replays": round(min_ms / args.steps * 1e3, 3),
+            "kernel_us_replays": [round(r / args.steps * 1e3, 3) for r in headline_timing.get("replays_ms", [])],
             "kernel_us_clock": headline_timing.get("clock"),
             "kernel_us_hip_events": round(hip_events_ms / args.steps * 1e3, 3),
             "kernel_us_rocprof": rocprof_us, "kernel_us_rocprof_median": rocprof_med_us,

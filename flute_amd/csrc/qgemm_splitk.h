@@ -128,6 +128,10 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
     constexpr int XA = (KP == 4) ? 2 : 3;
 #endif
     static_assert(XA == 2 || XA == 3, "activation request distance");
+    // (Measured and dropped in round 6, profiles/r06/call22_lookups_two_half_steps_ahead_dropped.log: the table lookups TWO half steps ahead with
+    // their scale multiplies between the MFMAs of the half step before they are needed - no LDS drain and no VALU in front of a half step's
+    // first MFMA; M = 256 on 4096^2 15.57 -> 15.9 us, bf16 16.7 -> 18.1: VALU between a wave's MFMAs delays its in-order MFMA issue by more
+    // than the multiplies cost in front of the barrier, where they overlap the wait for the slowest wave.)
     constexpr int WA = XA;                                         // weight request distance
     constexpr int NW = (dbg & 2) ? 0 : 1;                          // weight requests per compute wave and step in the loop
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;

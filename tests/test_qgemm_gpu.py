@@ -468,12 +468,14 @@ def test_skinny_mfma_kernel(env):
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2d, env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1, ref1), (bits, tile_p, g, dtype, K, N, M, waves)
             assert ran, (K, g)
-    # taken automatically on the Llama-2 / Llama-3 8B MLP widths; same results as the per-wave kernel within tolerance
-    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 4096, 11008
+    # taken automatically on the Llama-3 8B MLP width (11008: round 6 - the lean MFMA decode kernel with three column groups per workgroup);
+    # same results as the per-wave kernel within tolerance
+    bits, tile_p, g, dtype, K, N = 4, 32, 64, torch.float16, 4096, 14336
     W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=5)
     tid = template_ids_for(env.fa, bits, tile_p)[0]
     X = (torch.randn(16, K) / 100).to(dtype)
     assert dev.get_plan(16, N, K, bits, g, tid, env.num_sms, dtype)["family"] == 5
+    assert dev.get_plan(16, 11008, K, bits, g, tid, env.num_sms, dtype)["family"] == 7
     a = run_qgemm(env, X, Q, S, table, table2, bits, g, tid)
     b = run_qgemm(env, X, Q, S, table, table2, bits, g, tid, dict(family=2))
     assert rel_err(a, b.float()) < 5e-4
@@ -619,7 +621,7 @@ def test_block_prefill_kernel(env):
     assert p["family"] == 3 and p["m_block"] == 4 and p["grid"] == 256, p           # 256-row blocks, 1 x 8 split
     p = dev.get_plan(2048, 4096, 4096, 4, 64, 16, 256, torch.bfloat16)
     assert p["family"] == 3 and p["m_block"] == 5 and p["grid"] == 256, p           # 128-row blocks fill the chip
-    assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 2
+    assert dev.get_plan(256, 4096, 4096, 4, 64, 16, 256, torch.float16)["family"] == 6       # 64 x 64 tiles over all of K (round 6; rounds 2 - 5: the per-wave kernel)
     p = dev.get_plan(4096, 4096, 4096, 2, 64, 0, 256, torch.float16)
     assert p["family"] == 3 and p["m_block"] == 4, p                                 # 2-bit layers: the 1 x 8 split only
     p = dev.get_plan(4096, 4096, 4096, 3, 64, 4, 256, torch.bfloat16)

@@ -164,27 +164,47 @@ def test_plan_family6():
     assert _plan(256, 4096, 4096, family=4)[0] != 0 and _plan(256, 4096, 4096, family=8)[0] != 0   # unknown families are refused (7 = the lean MFMA decode kernel since round 5: falls back above M = 16)
 
 
-def test_xcd_pair_order_is_a_bijection():
-    """qgemm_splitk.h's XCD-aware tile order (splitk == 1): pairs of row tiles x column tile are dealt to the eight XCDs
-    (block b -> XCD b % 8) so that the two row tiles that share a column tile's weights run on ONE XCD; every tile is
-    produced exactly once for any tile grid, the incomplete last group of eight keeps the natural order."""
-    def remap(tile, tiles_m, tiles_n):
-        P = tiles_m // 2
-        if tiles_m < 2 or tiles_m % 2 or (P & (P - 1)):
+def test_xcd_group_order_is_a_bijection():
+    """qgemm_splitk.h's XCD-aware tile order (splitk == 1): groups of E = 1, 2, 4, 8 row tiles x column tile are dealt to the eight XCDs
+    (block b -> XCD b % 8) so that the E row tiles that share a column tile's weights run on ONE XCD (round 4: pairs; round 6: up to
+    eight - the four 64-row tiles of M = 256); every tile is produced exactly once for any tile grid, the incomplete last group of
+    eight keeps the natural order."""
+    def group_of(tiles_m, ovr=0):                                   # api.hip, plan_splitk: the largest of 8, 4, 2 that divides into a power of two
+        E = 8
+        while E > 1 and (tiles_m % E or ((tiles_m // E) & (tiles_m // E - 1))):
+            E >>= 1
+        if ovr in (1, 2, 4, 8):
+            E = ovr
+        if tiles_m % E or ((tiles_m // E) & (tiles_m // E - 1)):
+            E = 1
+        return E
+
+    def remap(tile, tiles_m, tiles_n, E):
+        if E < 2:
             return tile % tiles_m, tile // tiles_m                  # api.hip: pair_lg = -1
-        lg, c8 = P.bit_length() - 1, (P * tiles_n) & ~7
-        if tile < 2 * c8:
+        P = tiles_m // E
+        e_lg, lg, c8 = E.bit_length() - 1, P.bit_length() - 1, (P * tiles_n) & ~7
+        em = E - 1
+        if tile < (c8 << e_lg):
             i = tile >> 3
-            c, e = (i >> 1) * 8 + (tile & 7), i & 1
+            c, e = (i >> e_lg) * 8 + (tile & 7), i & em
         else:
-            c, e = tile >> 1, tile & 1
-        return 2 * (c & ((1 << lg) - 1)) + e, c >> lg
-    for tiles_m in (1, 2, 3, 4, 6, 8, 16):
-        for tiles_n in (1, 2, 7, 8, 9, 32, 86, 112, 224):
-            seen = {remap(t, tiles_m, tiles_n) for t in range(tiles_m * tiles_n)}
-            assert len(seen) == tiles_m * tiles_n and all(0 <= a < tiles_m and 0 <= b < tiles_n for a, b in seen)
-    # M = 256 on 4096 x 11008: the 22 (21) tiles of an XCD are 11-12 whole pairs
+            c, e = tile >> e_lg, tile & em
+        return ((c & ((1 << lg) - 1)) << e_lg) + e, c >> lg
+    for tiles_m in (1, 2, 3, 4, 6, 8, 12, 16):
+        for tiles_n in (1, 2, 7, 8, 9, 32, 64, 86, 112, 224):
+            for ovr in (0, 1, 2, 4, 8):
+                E = group_of(tiles_m, ovr)
+                seen = {remap(t, tiles_m, tiles_n, E) for t in range(tiles_m * tiles_n)}
+                assert len(seen) == tiles_m * tiles_n and all(0 <= a < tiles_m and 0 <= b < tiles_n for a, b in seen), (tiles_m, tiles_n, E)
+    assert group_of(4) == 4 and group_of(2) == 2 and group_of(8) == 8 and group_of(6) == 1 and group_of(3) == 1 and group_of(12) == 1 and group_of(16) == 8
+    # M = 256 on 4096 x 11008 (128-row tiles): the 22 (21) tiles of an XCD are 11-12 whole pairs
     per = {}
     for t in range(2 * 86):
-        per.setdefault(t % 8, []).append(remap(t, 2, 86))
+        per.setdefault(t % 8, []).append(remap(t, 2, 86, 2))
     assert all(len({tn for _, tn in v}) <= len(v) // 2 + 1 for v in per.values())
+    # M = 256 on 4096^2 (64 x 64 tiles, round 6): the 32 tiles of an XCD are the four row tiles of eight column tiles
+    per = {}
+    for t in range(4 * 64):
+        per.setdefault(t % 8, []).append(remap(t, 4, 64, 4))
+    assert all(len(v) == 32 and len({tn for _, tn in v}) == 8 for v in per.values())

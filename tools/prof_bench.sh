@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the bench command (run on the GPU box): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in their own PMC passes (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE x2 correction on gfx950).
-# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r05_bench_traffic.json - the file bench.py
+# Writes gpurun_out/prof/bench/summary.txt and gpurun_out/prof/bench/r06_bench_traffic.json - the file bench.py
 # reads `roofline.traffic` from (copy it to profiles/; it carries the plan it was measured on and bench.py
 # drops it the moment the live plan differs).
 set -u
@@ -49,6 +49,6 @@ rec = {"source": "tools/prof_bench.sh: rocprofv3 --kernel-trace --stats, then --
        "kernel_trace": trace, "kernel_trace_calls": ncalls, "kernel_us_rocprof_avg": None if avg_ns is None else round(avg_ns / 1e3, 4),
        "kernel_us_rocprof_median": None if med_ns is None else round(med_ns / 1e3, 4),
        "bench_untraced_ms_per_step": line["ms_per_step"]}
-json.dump(rec, open(out + "/r05_bench_traffic.json", "w"), indent=1)
+json.dump(rec, open(out + "/r06_bench_traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY

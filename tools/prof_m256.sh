@@ -1,6 +1,6 @@
 #!/bin/bash
 # BASELINE.json's second half (TFLOP/s at M = 256, W4G64 4096 x 4096): rocprofv3 kernel trace + PMC passes of the automatic plan under the
-# table's id, condensed into gpurun_out/prof/m256/r05_m256_pmc.json - the file bench.py's `m256` block reads traffic / MFMA-busy from
+# table's id, condensed into gpurun_out/prof/m256/r06_m256_pmc.json - the file bench.py's `m256` block reads traffic / MFMA-busy from
 # (copy it to profiles/; it carries the plan it was measured on and bench.py drops it the moment the live plan differs).
 set -u
 cd "$(dirname "$0")/.."
@@ -38,6 +38,6 @@ rec = {"source": "tools/prof_m256.sh: rocprofv3 --kernel-trace --stats, then fou
        "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_INSTS_MFMA": vals.get("SQ_INSTS_MFMA"), "SQ_INSTS_VALU": vals.get("SQ_INSTS_VALU"),
        "mfma_busy_frac_chip": None if not (busy and med_ns) else round(busy / (med_ns * 1e-9 * 2.4e9 * 1024), 4),
        "mfma_busy_formula": "SQ_VALU_MFMA_BUSY_CYCLES / (median kernel duration x 2.4 GHz x 1024 SIMDs)"}
-json.dump(rec, open("gpurun_out/prof/m256/r05_m256_pmc.json", "w"), indent=1)
+json.dump(rec, open("gpurun_out/prof/m256/r06_m256_pmc.json", "w"), indent=1)
 print(json.dumps(rec)[:1500])
 PY

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(1024) void read_kernel(const uint32_t* __restrict__
     extern __shared__ char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lkw = (geo >> 4) & 15, upw = (geo >> 8) & 31, pk = (geo >> 13) & 7;
+    const int lkw = (geo >> 4) & 15, upw = (geo >> 8) & 31, pk = (geo >> 13) & 15;     // (four bits: 8 pieces per wave in the lean kernel's shape)
     const int ul = wave >> lkw, kpart = wave & ((1 << lkw) - 1);
     const int unit = blockIdx.x * upw + ul;
     const srd_t srd = make_srd(reinterpret_cast<const char*>(Qp) + (size_t)unit * K * 2, (uint32_t)K * 2u);
@@ -327,7 +327,10 @@ int main(int argc, char** argv) {
     struct RV { const char* name; int W, kw, depth; bool nt; size_t lds; };
     const RV rvs[] = {{"read_w8_kw2_d4", 8, 2, 4, false, 0}, {"read_w8_kw2_d4_nt", 8, 2, 4, true, 0}, {"read_w8_kw2_d4_lds76k", 8, 2, 4, false, 76 * 1024},
                       {"read_w16_kw4_d2", 16, 4, 2, false, 0}, {"read_w8_kw4_d2", 8, 4, 2, false, 0}, {"read_w8_kw4_d2_lds76k", 8, 4, 2, false, 76 * 1024},
-                      {"read_w4_kw2_d4", 4, 2, 4, false, 0}, {"read_w4_kw4_d2", 4, 4, 2, false, 0}, {"read_w4_kw4_d2_nt", 4, 4, 2, true, 0}};
+                      {"read_w4_kw2_d4", 4, 2, 4, false, 0}, {"read_w4_kw4_d2", 4, 4, 2, false, 0}, {"read_w4_kw4_d2_nt", 4, 4, 2, true, 0},
+                      // round 6: the lean decode kernel's own launch shape (qgemm_fast.h: 256 workgroups x 4 waves x 8 pieces, nt loads, 72.6 KB of LDS)
+                      {"read_w4_kw1_d8", 4, 1, 8, false, 0}, {"read_w4_kw1_d8_nt", 4, 1, 8, true, 0}, {"read_w4_kw1_d8_nt_lds73k", 4, 1, 8, true, 73 * 1024},
+                      {"read_w8_kw2_d4_nt_lds73k", 8, 2, 4, true, 73 * 1024}};
     for (const RV& r : rvs) {
         const int pk = (npieces + r.kw - 1) / r.kw;
         if (pk > r.depth) continue;
@@ -335,7 +338,8 @@ int main(int argc, char** argv) {
         const uint32_t geo = OneGeo::pack(lg, lkw, upw, pk, 0, 0, 0);
         const int grid = units / upw;
         void (*fn)(const uint32_t*, uint32_t*, int, uint32_t) =
-            r.depth == 4 ? (r.nt ? read_kernel<4, true> : read_kernel<4, false>) : (r.nt ? read_kernel<2, true> : read_kernel<2, false>);
+            r.depth == 8 ? (r.nt ? read_kernel<8, true> : read_kernel<8, false>)
+                         : (r.depth == 4 ? (r.nt ? read_kernel<4, true> : read_kernel<4, false>) : (r.nt ? read_kernel<2, true> : read_kernel<2, false>));
         CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         auto launch = [&](int c) { hipLaunchKernelGGL(fn, dim3(grid), dim3(r.W * 64), r.lds, st, d.Q + (size_t)c * d.qwords, d.sink, K, geo); };
         printf("{\"variant\": \"%s\", \"tag\": \"%s\", \"N\": %d, \"K\": %d, \"grid\": %d, \"us\": %.3f}\n", r.name, tag, N, K, grid, time_graph(st, d.ncopy, 8, launch));
