@@ -128,6 +128,11 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
     constexpr int XA = (KP == 4) ? 2 : 3;
 #endif
     static_assert(XA == 2 || XA == 3, "activation request distance");
+#ifdef FLUTE_SK_TWO_BARRIERS   // development A/B: both barriers of a step at request distance 3 too (rounds 4 / 5)
+    constexpr bool ONE_BARRIER = false;
+#else
+    constexpr bool ONE_BARRIER = true;
+#endif
     // (Measured and dropped in round 6, profiles/r06/call22_lookups_two_half_steps_ahead_dropped.log: the table lookups TWO half steps ahead with
     // their scale multiplies between the MFMAs of the half step before they are needed - no LDS drain and no VALU in front of a half step's
     // first MFMA; M = 256 on 4096^2 15.57 -> 15.9 us, bf16 16.7 -> 18.1: VALU between a wave's MFMAs delays its in-order MFMA issue by more
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nsteps; ++t) {
-            __builtin_amdgcn_s_barrier();                          // (A) XA = 2: stage t-1 is free
+            if constexpr (XA == 2 || !ONE_BARRIER) __builtin_amdgcn_s_barrier();      // (A) XA = 2: stage t-1 is free
             if constexpr (!(dbg & 1) && XA == 2) lbatch(t + 2);
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW) : "memory");   // batch t+1 has landed (one younger batch may be on its way)
             __builtin_amdgcn_s_barrier();                          // (B) stage t+1 is complete; stage t has been read by every wave
@@ -408,8 +413,9 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
         scales(nxt_t{}, t + h, nh);
         const u32x4_t qw = half_words(w[nslot], nxt_t{});
         asm volatile("" : "+v"(bf[0]), "+v"(bf[1]) : : "memory");     // (keeps hipcc from sinking the multiplies below the barrier)
-        // (A) [h = 0]; (B) [h = 1] stage t+1 is complete (and stage t free)
-        if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
+        // (A) [h = 0]; (B) [h = 1] stage t+1 is complete (and stage t free).  At request distance 3 nobody needs (A): the stage half step 0
+        // reads next was complete at the previous (B), and the loaders refill a stage behind (B) only
+        if constexpr (!(dbg & 32) && !(h == 0 && XA == 3 && ONE_BARRIER)) __builtin_amdgcn_s_barrier();
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
 #pragma unroll
