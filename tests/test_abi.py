@@ -457,3 +457,36 @@ def test_round5_planner_rules():
     assert rc == 0 and (p.one_shot, p.grid) == (4, 512), p.as_dict()
     assert plan(4, 8192, 2048)[1].one_shot != 4 and plan(2, 16384, 2048)[1].one_shot != 4
 
+
+
+def test_round6_planner_rules():
+    """Round 6, as host logic: the split-K block kernel's 64 x 64 tiles (four K parts per workgroup) where they fill at least half
+    the chip in one round (measured: profiles/r06/call17_automatic_plan_vs_forced.log), XCD groups of up to eight row tiles, and the
+    lean MFMA decode kernel's column groups per workgroup (profiles/r06/call18_fastm_column_groups.log)."""
+    def sk(M, N, K, **kw):
+        rc, p = plan(M, N, K, **kw)
+        assert rc == 0, (M, N, K)
+        return (p.family, p.m_tiles, p.kw, p.splitk, p.grid, p.m_block)
+    assert sk(256, 4096, 4096) == (6, 4, 4, 1, 256, 4)                 # all of K per workgroup: no seam; the four row tiles of a column tile on one XCD
+    assert sk(192, 4096, 4096) == (6, 4, 4, 1, 192, 1)                 # three row tiles: natural order
+    assert sk(128, 4096, 4096) == (6, 4, 4, 2, 256, 1)                 # two K slices, combined in the launch (L form: one row tile per wave)
+    assert sk(512, 2048, 4096) == (6, 4, 4, 1, 256, 8)
+    assert sk(256, 2048, 8192) == (6, 4, 4, 2, 256, 1)
+    assert sk(256, 11008, 4096) == (6, 8, 2, 1, 172, 2)                # more than one round of 64 x 64 tiles: 128-row tiles as before
+    assert sk(1024, 4096, 4096) == (6, 8, 2, 1, 256, 8)
+    rc, p = plan(256, 4096, 4096)
+    assert p.lds_bytes == 32768 + 4 * 3 * 8192 + 2 * 4096 and p.workspace_needed == 0 and p.splitk_mode == 0 and p.block == 768
+    rc, p = plan(256, 4096, 4096, ovr=_lib.Overrides(family=6, kw=2))  # rounds 4 / 5: 64 x 128 tiles x two slices
+    assert rc == 0 and (p.kw, p.m_tiles, p.splitk, p.grid, p.splitk_mode) == (2, 4, 2, 256, 1)
+    assert plan(256, 4096, 4096, ovr=_lib.Overrides(family=6, waves=8))[0] != 0          # the variant without loader waves is gone
+    assert plan(256, 4096, 4096, ovr=_lib.Overrides(family=6, kw=4, m_tiles=8))[0] != 0  # four K parts: 64-row tiles only (LDS)
+    assert plan(256, 4096, 8192, ovr=_lib.Overrides(family=6, kw=4, splitk=1))[0] != 0   # 128 groups per workgroup K range: more than one scale image holds
+    assert plan(256, 4096, 8192, ovr=_lib.Overrides(family=6, kw=4, splitk=2))[0] == 0
+    # lean MFMA decode kernel: the fewest column groups per workgroup that make one round
+    for (N, ng, grid) in ((4096, 1, 256), (5120, 2, 160), (6144, 2, 192), (8192, 2, 256), (11008, 3, 230)):
+        rc, p = plan(16, N, 4096)
+        assert rc == 0 and (p.family, p.slabs_per_wave, p.grid) == (7, ng, grid), (N, p.as_dict())
+    rc, p = plan(16, 14336, 4096)
+    assert rc == 0 and p.family == 5                                    # 299 workgroups at three groups: more than one round
+    rc, p = plan(16, 11008, 4096, ovr=_lib.Overrides(family=7, slabs_per_wave=1))
+    assert rc == 0 and (p.family, p.slabs_per_wave, p.grid) == (7, 1, 688)

@@ -95,7 +95,8 @@ def served_template(e, M, N, K, bits, g, dtype, tile_p):
     FluteLinear / tune_and_pack / bench.py take it (flute_amd/data/gfx950_tuned.json, ~9.5 k keys: ids 28, 12, 5, 29, 24, 20, 18, ...)
     - when it exists and shares the packed matrix's TileP; else the first id of that TileP (the automatic plan)."""
     from flute_amd import tune
-    tid = tune.lookup_tuned(M, N, K, bits, g, e.num_sms, dtype, 32 if tile_p == 32 else None)
+    # (the table keys 2- / 4-bit layers twice - any TileP, and TileP 32 - and 3-bit layers, which exist for TileP 32 only, once)
+    tid = tune.lookup_tuned(M, N, K, bits, g, e.num_sms, dtype, 32 if (tile_p == 32 and bits != 3) else None)
     if tid is not None and e.fa.TEMPLATE_CONFIGS[(bits, tid)]["TileP"] == tile_p and \
             e.utils.is_template_supported(M, N, K, bits, tid, e.num_sms, g, dtype):
         return tid

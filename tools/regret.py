@@ -56,6 +56,7 @@ def candidates(bits, M):
               dict(family=2, m_block=1, kw=4), dict(family=2, m_block=1, kw=2)]
     if 3 <= M <= 16 and bits == 4:
         c += [dict(family=5, splitk=sk) for sk in (1, 2, 4, 8)]
+        c += [dict(family=7, slabs_per_wave=ng) for ng in (1, 2, 3)]          # lean MFMA decode kernel: column groups per workgroup (round 6)
     if bits == 3 and 17 <= M <= 64:
         c += [dict(family=3, m_block=4), dict(family=3, m_block=2)]
     if bits == 3 and M > 64:
@@ -64,6 +65,8 @@ def candidates(bits, M):
         c += [dict(family=3, m_tiles=4), dict(family=3, m_tiles=8)]
         if bits != 3:
             c += [dict(family=6, splitk=sk) for sk in (1, 2, 4, 8)]
+    if M >= 33 and bits != 3:                                                  # split-K block kernel: every tile form x K slices (round 6: 64 x 64 tiles)
+        c += [dict(family=6, splitk=sk, kw=kw, m_tiles=rt) for (kw, rt) in ((4, 4), (2, 4), (2, 8)) for sk in (1, 2, 4)]
     return c
 
 
