@@ -698,7 +698,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // (overrides of the per-wave kernel - m_tiles, waves, kw, splitk, slabs - mean something else in plan_splitk: a call that sets
     // any of them without family = 6 keeps the per-wave / block kernels)
     const bool wave_ovr = ov.m_tiles > 0 || ov.waves > 0 || ov.kw > 0 || ov.splitk > 0 || ov.slabs > 0 || ov.m_block > 0;
-    const bool sk_regime = ov.family < 0 && !wave_ovr && family == 2 && bits != 3 && (M >= 128 || (bits == 4 && M >= 33) || (bits == 2 && M >= 65)) && auto_digit_sk(bits, template_id);
+    const bool sk_regime = ov.family < 0 && !wave_ovr && family == 2 && bits != 3 && (M >= 128 || M >= 33) && auto_digit_sk(bits, template_id);      // (2 bits: from M = 65 until round 6 - with 64 x 64 tiles M = 48 / 64 gain 25 - 43 %: profiles/r06/planner_regret_before_fixes.json)
     if (sk_regime && t.stages == 5 && M > 64) {       // (M <= 64: the table's Stages-5 ids of that bucket were tuned on the per-wave kernel's K split)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, p, t.sms_multiple == 1 ? 0 : (t.sms_multiple == 2 ? 1 : 2)) == FLUTE_OK)
             return FLUTE_OK;

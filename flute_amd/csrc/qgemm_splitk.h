@@ -265,53 +265,34 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
             lx[i] = (uint32_t)(((size_t)(m0 + rt * 16 + rh * 8 + row8) * a.K + (((lane & 7) ^ sk_swz(row8, rh)) * 8)) * 2);
         }
         const uint32_t ldst = (uint32_t)X_BASE + (uint32_t)lkh * (BLK_STAGES * SK_STAGE) + (uint32_t)lp0 * 1024u;
-        auto lpart = [&](int u, auto lo_tag, auto hi_tag) {        // pieces lo .. hi - 1 of batch u
+        auto lbatch = [&](int u) {
             const uint32_t k0 = (uint32_t)(lkbeg + min(u, nsteps - 1) * KSTEP);
             const uint32_t dst = ldst + (uint32_t)(u % BLK_STAGES) * SK_STAGE;
             const srd_t d = live(x_srd, u);
 #pragma unroll
-            for (int i = decltype(lo_tag)::value; i < decltype(hi_tag)::value; ++i) dma16_buf(lx[i], d, k0 * 2u, dst + (uint32_t)i * 1024u);
+            for (int i = 0; i < LPW; ++i) dma16_buf(lx[i], d, k0 * 2u, dst + (uint32_t)i * 1024u);
         };
-        auto lbatch = [&](int u) { lpart(u, std::integral_constant<int, 0>{}, std::integral_constant<int, LPW>{}); };
-#ifdef FLUTE_SK_PRE3      // development A/B (XA = 2): the prologue asks for batch 2 as well (its stage is free), step 0 issues nothing
-        constexpr bool PRE3 = XA == 2;
-#else
-        constexpr bool PRE3 = false;
-#endif
-#ifdef FLUTE_SK_LATE      // development A/B (XA = 2): batch t + 2 behind barrier (B) of step t, ONE barrier per step, one step of flight
-        constexpr bool LATE = XA == 2;
-#else
-        constexpr bool LATE = false;
-#endif
-        constexpr int XP = (XA == 3 || PRE3) ? 3 : 2;             // batches the prologue asks for
+        // (Measured and dropped at request distance 2, profiles/r06/call24_issue_points_dropped.log, M = 256 on 4096^2: a third batch in the
+        // prologue 15.0 us, half of a batch behind each barrier 15.0, the batch behind barrier (B) with one barrier per step 15.4 - against 14.8 - 15.4.)
         lbatch(0);
         lbatch(1);
-        if constexpr (XP == 3) lbatch(2);
+        if constexpr (XA == 3) lbatch(2);
         [&]<int... R>(std::integer_sequence<int, R...>) {
             ([&] {
-                const uint32_t lv = lut_word_after<LUT_R - 1 - R + XP * LPW>(lutw[R]);
+                const uint32_t lv = lut_word_after<LUT_R - 1 - R + XA * LPW>(lutw[R]);
                 const int p = tid + NTHR * R;
                 if (p < ENT * 8) *reinterpret_cast<uint4*>(smem + (size_t)(p >> 3) * 128 + (p & 7) * 16) = make_uint4(lv, lv, lv, lv);
             }(), ...);
         }(std::make_integer_sequence<int, LUT_R>{});
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((XP - 1) * LPW) : "memory");   // batch 0 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((XA - 1) * LPW) : "memory");   // batch 0 has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nsteps; ++t) {
-            if constexpr ((XA == 2 && !LATE) || !ONE_BARRIER) __builtin_amdgcn_s_barrier();      // (A) XA = 2: stage t-1 is free
-#ifdef FLUTE_SK_SPLIT     // development A/B (XA = 2): half of batch t + 2 behind (A), the other half behind (B)
-            if constexpr (!(dbg & 1)) lpart(t + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, LPW / 2>{});
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW / 2) : "memory");
-            __builtin_amdgcn_s_barrier();
-            if constexpr (!(dbg & 1)) lpart(t + 2, std::integral_constant<int, LPW / 2>{}, std::integral_constant<int, LPW>{});
-            continue;
-#endif
-            if constexpr (!(dbg & 1) && XA == 2 && !LATE) { if (!PRE3 || t > 0) lbatch(t + 2); }
-            if constexpr (LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW) : "memory");   // batch t+1 has landed (one younger batch may be on its way)
+            if constexpr (XA == 2 || !ONE_BARRIER) __builtin_amdgcn_s_barrier();      // (A) XA = 2: stage t-1 is free
+            if constexpr (!(dbg & 1) && XA == 2) lbatch(t + 2);
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPW) : "memory");   // batch t+1 has landed (one younger batch may be on its way)
             __builtin_amdgcn_s_barrier();                          // (B) stage t+1 is complete; stage t has been read by every wave
             if constexpr (!(dbg & 1) && XA == 3) lbatch(t + 3);    // ... and takes batch t+3
-            if constexpr (!(dbg & 1) && LATE) lbatch(t + 2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;                                                    // the epilogue's barriers count the live waves only
@@ -436,12 +417,7 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
         asm volatile("" : "+v"(bf[0]), "+v"(bf[1]) : : "memory");     // (keeps hipcc from sinking the multiplies below the barrier)
         // (A) [h = 0]; (B) [h = 1] stage t+1 is complete (and stage t free).  At request distance 3 nobody needs (A): the stage half step 0
         // reads next was complete at the previous (B), and the loaders refill a stage behind (B) only
-#ifdef FLUTE_SK_LATE
-        constexpr bool no_a = h == 0 && ONE_BARRIER;
-#else
-        constexpr bool no_a = h == 0 && XA == 3 && ONE_BARRIER;
-#endif
-        if constexpr (!(dbg & 32) && !no_a) __builtin_amdgcn_s_barrier();
+        if constexpr (!(dbg & 32) && !(h == 0 && XA == 3 && ONE_BARRIER)) __builtin_amdgcn_s_barrier();
         auto row = [&](auto r_tag) {
             constexpr int R = decltype(r_tag)::value;
 #pragma unroll

@@ -74,8 +74,8 @@ def test_plan_families_and_invariants():
                 want = 6                             # 2 / 4 bits: 8 x 32 tiles of 128 x 128, one per CU (qgemm_splitk.h, round 4)
             if bits != 3 and M == 256:
                 want = 6                             # ... and 4 x 64 tiles of 64 x 64 over all of K (four K parts per workgroup, round 6)
-            if bits == 4 and M == 64:
-                want = 6                             # ... x 4 K slices at M = 64 (4 bits from M = 33)
+            if bits != 3 and M == 64:
+                want = 6                             # ... x 4 K slices at M = 64 (from M = 33; 2 bits: from 65 until round 6)
             if bits == 4 and 5 <= M <= 16:
                 want = 7                             # 4 bits, K = 4096, one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
@@ -159,7 +159,9 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 2
     rc, p = plan(96, 8192, 8192, bits=2, tid=0)
     assert rc == 0 and (p.family, p.m_tiles, p.splitk, p.grid) == (6, 4, 2, 256)     # 2-bit layers from M = 65
-    rc, p = plan(64, 8192, 8192, bits=2, tid=0)
+    rc, p = plan(64, 8192, 8192, bits=2, tid=0)                   # round 6: 2-bit layers from M = 33 too (64 x 64 tiles: 20.8 -> 17.9 us)
+    assert rc == 0 and (p.family, p.m_tiles, p.kw, p.splitk, p.grid) == (6, 4, 4, 2, 256)
+    rc, p = plan(32, 8192, 8192, bits=2, tid=0)
     assert rc == 0 and p.family == 2
     rc, p = plan(64, 8192, 8192, tid=17)
     assert rc == 0 and p.family == 2                    # a tuned id (QuantMapMode digit 1) keeps the kernel it was timed on
@@ -333,7 +335,7 @@ def test_plan_invariants_over_random_shapes():
         elif p.family == 6:                                       # split-K block kernel (qgemm_splitk.h's host contract)
             assert p.m_tiles in (8, 4) and p.kw in (2, 4) and (p.kw == 2 or p.m_tiles == 4), what      # 128- / 64-row tiles; K parts per workgroup (round 6: 4 = 64-column tiles)
             tiles = -(-M // (p.m_tiles * 16)) * (N // (256 // p.kw))
-            assert bits in (2, 4) and M >= (33 if bits == 4 else 65) and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
+            assert bits in (2, 4) and M >= 33 and p.block == 768 and p.waves == 12 and p.grid == tiles * p.splitk, what
             assert p.k_per_split * p.splitk == K and p.k_per_split % (p.kw * max(64, g)) == 0 and (K // g) % 8 == 0 and N % 128 == 0, what
             gw = p.k_per_split // g                               # one scale image of eight 8-group blocks per column group
             assert gw + (7 if gw % 8 else 0) <= 64, what
