@@ -23,8 +23,10 @@
 extern "C" {
 #endif
 
-/* 6 (round 5): flute_plan.one_shot / flute_overrides.one_shot value 4 (lean decode kernel, qgemm_fast.h), flute_debug_timestamp */
-#define FLUTE_AMD_ABI_VERSION 6
+/* 7 (round 6): same structs; flute_plan.kw / m_block of family 6 = K parts per workgroup (2 / 4) / row tiles per XCD group, flute_plan.slabs_per_wave
+ *    of family 7 = column groups per workgroup (1 .. 3), and the overrides of the same names select them; family 6 refuses waves = 8
+ * 6 (round 5): flute_plan.one_shot / flute_overrides.one_shot value 4 (lean decode kernel, qgemm_fast.h), flute_debug_timestamp */
+#define FLUTE_AMD_ABI_VERSION 7
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
