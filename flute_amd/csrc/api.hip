@@ -437,7 +437,11 @@ int plan_splitk(int bits, int lg, int M, int N, int K, int num_sms, const Ovr& o
     // ~1 + 0.15 / MB, 4 slices and the L form ~1.5 + 0.5 / MB)
     auto model_us = [&](int sk, int rt, int kp) {
         const long wgs = tiles_of(rt, kp) * sk;
-        const long rounds = (wgs + num_sms - 1) / num_sms;
+        // a last, partly filled round costs less than a whole one (round 6: M = 384 on 8192^2, 128-row tiles x 2 slices = 1.5 rounds: 68 us
+        // measured, 83 priced at two whole rounds - and the cheaper-looking 64-row plan, three whole rounds, ran 81): the mean of
+        // the whole rounds and the exact share (profiles/r06_planner_regret_between_final.json)
+        const double whole = (double)((wgs + num_sms - 1) / num_sms);
+        const double rounds = wgs <= (long)num_sms ? 1.0 : 0.5 * (whole + (double)wgs / num_sms);
         const double fill = std::min(1.0, (double)wgs / num_sms);
         const double steps = (double)K / sk / (64.0 * kp);     // 64-k steps of a K part
         const int hr = rt / kp;
@@ -753,7 +757,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // (3 bits, round 4: 14336 x 3584 M = 256 runs at 305, modelled 370 kept it off the 128-row blocks: 86.4 against 70.3 us; round 5's
             // regret sweep, fp16: 3584 x 8192 M = 256 293, 14336 x 3584 M = 128 276, 8192^2 M = 96 253 - fewer rows, fewer MFMAs per lookup)
             const double wave_tf = (bits == 3) ? (bf ? 290.0 : 300.0) * (M >= 256 ? 1.0 : 0.6 + 0.4 * M / 256.0)
-                                   : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl));
+                                   : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl)) * (bits == 2 ? 0.65 : 1.0);   // (2 bits: see below)
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
             else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
@@ -803,6 +807,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             int dbl = M < 256 ? -1 : 0;
             for (int m = M; m >= 512; m >>= 1) ++dbl;
             double wave_tf = bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl);
+            // (2-bit layers: twice the lookups per byte - the per-wave kernel ran M = 384 on 4096^2 at 316 TFLOP/s where the 4-bit layer runs 503:
+            // profiles/r06_planner_regret_between_final.json)
+            if (bits == 2) wave_tf *= 0.65;
             if (M < 128) {
                 // per-wave kernel below M = 128 (measured fp16, tools/time_cases.py): 220 .. 280 TFLOP/s at M = 48, 270 .. 350 at
                 // M = 64 .. 96 on layers up to 14336 columns; 490 .. 570 on 28672 columns (two slabs per wave, every CU busy)

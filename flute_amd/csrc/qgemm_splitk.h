@@ -551,6 +551,8 @@ __global__ __launch_bounds__(SK_THREADS) void qgemm_splitk_kernel(const SplitKAr
             uint2 o;
             o.x = (uint32_t)NT::from_float(__builtin_bit_cast(float, f[0])) | ((uint32_t)NT::from_float(__builtin_bit_cast(float, f[1])) << 16);
             o.y = (uint32_t)NT::from_float(__builtin_bit_cast(float, f[2])) | ((uint32_t)NT::from_float(__builtin_bit_cast(float, f[3])) << 16);
+            // (write-through - sc1 - output stores, so that the bytes leave the L2 when stored and not at the end-of-kernel write-back: equal on
+            // 64-row tiles, 128-row tiles 31.5 -> 33.0 us; profiles/r06/call25_write_through_output_stores_dropped.log)
             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.D) + (size_t)row * a.N + col[t]) = o;
         }
     };
