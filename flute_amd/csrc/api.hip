@@ -20,6 +20,7 @@
 #include "qgemm_persist.h"
 #include "qgemm_fast.h"
 #include "qgemm_fastm.h"
+#include "qgemm_persistm.h"
 #include "qgemm_skinny.h"
 #include "mfma.h"
 #include "qgemm_tile.h"
@@ -43,6 +44,7 @@ constexpr int kFamilyBlock = 3;                 // block-tiled prefill kernel (q
 constexpr int kFamilySkinny = 5;                // registers-only MFMA kernel for 3 <= M <= 32 (qgemm_skinny.h)
 constexpr int kFamilySplitK = 6;                // 128 / 64 x 128 / 64 tiles, K split over workgroups, combined in the launch (qgemm_splitk.h)
 constexpr int kFamilyFastM = 7;                 // lean MFMA decode kernel: 4 unit rows x all of K per workgroup, M <= 16 (qgemm_fastm.h)
+constexpr int kFamilyPersistM = 8;              // persistent MFMA decode kernel: workgroups stream column-group sets x all of K, M <= 16 (qgemm_persistm.h)
 // Workspace layout (every kernel): [0, kXwgFlagBytes) tile state words of the in-launch reductions (xwg.h; zero between
 // calls), fp32 slabs behind them.  A planner sees the room behind the state words only.
 size_t slab_room(size_t workspace_bytes) { return workspace_bytes > kXwgFlagBytes ? workspace_bytes - kXwgFlagBytes : 0; }
@@ -300,6 +302,49 @@ int plan_fastm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, f
     p->lds_bytes = fastm_lds_bytes(K); p->lut_copies = 32;
     p->ring_depth = nm; p->visits = 1; p->k_chunks = 1; p->one_shot = 0;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = nm; }
+    return FLUTE_OK;
+}
+
+// Persistent MFMA decode kernel (qgemm_persistm.h, round 6): 4 bits, M <= 16, K a multiple of 128 (>= 1024), group size 64 / 128.  A set =
+// ng column groups (16 columns each); the sets are dealt round-robin to `grid` workgroups, `visits` sets each (the last round may be short);
+// grid = the fewest workgroups that keep `visits` whole rounds.  ng (override slabs_per_wave) by the model below; visits by override m_tiles.
+// Model (us): 3.3 fixed + the larger of the weights at the HBM rate the decode kernels reach (5.3 TB/s, scaled by the busiest workgroup's
+// share) and what the busiest workgroup pulls through its CU - its sets' weights + once per set the activations (4 ceil(M / 4) rows) - at 60 GB/s.
+double persistm_model_us(int M, int N, int K, int num_sms, int ng, int* grid_out, int* visits_out, int visits_ovr) {
+    const int groups = N / 16;
+    const int nsets = ceil_div(groups, ng);
+    int visits = ceil_div(nsets, num_sms);
+    if (visits_ovr >= 1) visits = visits_ovr;
+    int grid = ceil_div(nsets, visits);
+    if (grid > num_sms) { grid = num_sms; visits = ceil_div(nsets, grid); }
+    const double w_set = 8.0 * ng * K, x_set = 8.0 * ((M + 3) / 4) * K;
+    const double hbm = ((double)N * K / 2) / 5.3e6 * ((double)visits * grid * ng / groups) * ((double)num_sms / grid > 1.0 ? 1.0 : 1.0);
+    const double fill = visits * (w_set + x_set) / 60e3;
+    if (grid_out) *grid_out = grid;
+    if (visits_out) *visits_out = visits;
+    return 3.3 + (hbm > fill ? hbm : fill);
+}
+int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, int visits_ovr, flute_plan* p, OneArgs* oa) {
+    // (group size 128: a column's scale row must be a whole number of dwords - the macro-step's 4-B scale request)
+    if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 7 || K % 128 || (lg == 7 && K % 256) || K < 1024 || N % 16) return FLUTE_ERR_SHAPE;
+    if ((size_t)N * K / 2 >= (size_t)0xfffffff0u || (size_t)N * (size_t)(K >> lg) * 2 >= (size_t)0xfffffff0u || (size_t)M * K * 2 >= (size_t)0xfffffff0u)
+        return FLUTE_ERR_SHAPE;
+    int ng = 1, grid = 0, visits = 0;
+    double best = 0;
+    for (int c = 1; c <= 3; ++c) {
+        const double us = persistm_model_us(M, N, K, num_sms, c, nullptr, nullptr, visits_ovr);
+        if (c == 1 || us < best) { best = us; ng = c; }
+    }
+    if (ng_ovr >= 1 && ng_ovr <= 3) ng = ng_ovr;
+    (void)persistm_model_us(M, N, K, num_sms, ng, &grid, &visits, visits_ovr);
+    memset(p, 0, sizeof(*p));
+    p->family = kFamilyPersistM;
+    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = ng; p->waves = PM_W; p->kw = PM_W; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)grid; p->block = (unsigned)(PM_W * 64);
+    const int xr = M <= 4 ? 1 : (M <= 8 ? 2 : 4);                  // activation requests per macro-step (4 rows each)
+    p->lds_bytes = persistm_lds_bytes(ng, xr); p->lut_copies = 32;
+    p->ring_depth = PM_DW; p->visits = visits; p->k_chunks = xr; p->one_shot = 0;
+    if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = PM_DW; }
     return FLUTE_OK;
 }
 
@@ -591,8 +636,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
               StreamArgs* sa, OneArgs* oa) {
     if (dtype != 0 && dtype != 1) return FLUTE_ERR_DTYPE;
     // override families: -1 automatic, 0 decode, 1 / 2 per-wave MFMA kernel, 3 block kernels, 5 skinny MFMA kernel,
-    // 6 split-K block kernel, 7 lean MFMA decode kernel; anything else is a caller error (round 1's family 4 is gone)
-    if (ov.family < -1 || ov.family == 4 || ov.family > 7) return FLUTE_ERR_SHAPE;
+    // 6 split-K block kernel, 7 lean MFMA decode kernel, 8 persistent MFMA decode kernel; anything else is a caller error (round 1's family 4 is gone)
+    if (ov.family < -1 || ov.family == 4 || ov.family > 8) return FLUTE_ERR_SHAPE;
     if (bits != 2 && bits != 3 && bits != 4) return FLUTE_ERR_NUM_BITS;
     if (group != 32 && group != 64 && group != 128 && group != 256) return FLUTE_ERR_GROUP_SIZE;
     flute_template_info t;
@@ -658,6 +703,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const bool fastm_auto = ov.family < 0 && bits == 4 && M >= 5 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 &&
                             (K == 4096 || K == 2048) && fm_wgs <= (long)num_sms && fm_wgs * 2 >= (long)num_sms &&
                             ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0;
+    if (ov.family == kFamilyPersistM) return plan_persistm(bits, lg, M, N, K, num_sms, ov.slabs, ov.m_tiles, p, oa);
     if (ov.family == kFamilyFastM || fastm_auto) {
         if (plan_fastm(bits, lg, M, N, K, num_sms, ov.family == kFamilyFastM ? ov.slabs : -1, p, oa) == FLUTE_OK) return FLUTE_OK;
         memset(p, 0, sizeof(*p));
@@ -1277,6 +1323,21 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
         void* kargs[] = {&q32, &S, &A, &qm2, &K, &N, &geo, &nvis, &D, &hs, &nwg};
         if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) !=
             hipSuccess) {
+            (void)hipGetLastError();
+            return FLUTE_ERR_LAUNCH;
+        }
+        return FLUTE_OK;
+    }
+
+    if (p.family == kFamilyPersistM) {
+        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks) : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks);
+        if (!fn) return FLUTE_ERR_TEMPLATE_ID;
+        if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);
+        const uint32_t* qm2 = reinterpret_cast<const uint32_t*>(QM2);
+        int nsets = ceil_div(N / 16, p.slabs_per_wave);
+        void* kargs[] = {&q32, &S, &A, &qm2, &D, &N, &K, &M, &nsets};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(p.grid), dim3(p.block), kargs, p.lds_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             return FLUTE_ERR_LAUNCH;
         }

@@ -46,6 +46,11 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     constexpr int BATCH = PPW + 1 + 1;                             // X pieces, one weight piece, one scale block
     constexpr int LUT_BYTES = (1 << (2 * BITS)) * 128;
     constexpr int STAGE_BYTES = PIECES * 1024;
+#ifdef FLUTE_B2_ABLATE   // development builds (tools/build_variant.sh): 1 no activation requests in the loop, 2 no weight / scale requests,
+    constexpr int dbg = FLUTE_B2_ABLATE;                           // 4 no MFMA, 8 no table lookups, 16 no fragment reads, 32 no barriers
+#else
+    constexpr int dbg = 0;
+#endif
 
     BlockArgs a = args;
     {
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         constexpr int i = decltype(i_tag)::value;
         const uint32_t k0 = (uint32_t)(kbeg + min(u, nsteps - 1) * 64);
         if constexpr (i < PH) {
-            dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+            if constexpr (!(dbg & 1)) dma16_buf(x_vo[i], x_srd, k0 * 2u, x_lds0 + (uint32_t)i * 1024u + (uint32_t)slot * STAGE_BYTES);
+        } else if constexpr (dbg & 2) {
         } else if constexpr (i < PH + 1) {
             w[slot] = buf_load16(w_voff, w_srd, k0 * 2u);
         } else {
@@ -198,9 +204,10 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
     auto lookup = [&](const u32x4_t& qw, auto n_tag) {
         constexpr int n = decltype(n_tag)::value;                  // tile n / 4, word n % 4
         const uint32_t idx = __builtin_amdgcn_ubfe(qw[n & 3], shift0 + (uint32_t)(FB * FPT * (n >> 2)), (uint32_t)FB);
-        v[n] = lds_lookup32((idx << 7) | lane_off);
+        if constexpr (dbg & 8) v[n] = idx; else v[n] = lds_lookup32((idx << 7) | lane_off);
     };
     auto frag = [&](auto slot_tag, auto h_tag, auto r_tag) {
+        if constexpr (dbg & 16) return;
         constexpr int R = decltype(r_tag)::value;
         constexpr int off = decltype(slot_tag)::value * STAGE_BYTES + R * 2048;
         constexpr int hh = decltype(h_tag)::value;
@@ -230,12 +237,13 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
         constexpr int nh = h ^ 1;
         wait_lds();
         if constexpr (h == 0) {
-            __builtin_amdgcn_s_barrier();                          // (A) stage t-1 is free: batch t+2 follows, spread over the rows
+            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();   // (A) stage t-1 is free: batch t+2 follows, spread over the rows
         } else {
             // (B) batch t+1 has landed once at most batch t+2 is outstanding (SPLIT: only its PH activation pieces have
             // been issued by now; its weight / scale requests follow during this half step)
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(SPLIT ? PH : BATCH) : "memory");
-            __builtin_amdgcn_s_barrier();
+            constexpr int NB = ((dbg & 1) ? 0 : PH) + ((dbg & 2) ? 0 : 2);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[nslot]) : "n"(SPLIT ? ((dbg & 1) ? 0 : PH) : NB) : "memory");
+            if constexpr (!(dbg & 32)) __builtin_amdgcn_s_barrier();
         }
         u32x4_t bf[NT2];
 #pragma unroll
@@ -258,7 +266,10 @@ __global__ __launch_bounds__(512) void qgemm_block2_kernel(const BlockArgs args)
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(slot_reg) : "n"(7 + (R - 8)) : "memory");
             }
 #pragma unroll
-            for (int c = 0; c < NT2; ++c) acc[R][c] = Mfma<T>::run(bf[c], af[R & 7], acc[R][c]);
+            for (int c = 0; c < NT2; ++c) {
+                if constexpr (dbg & 4) acc[R][c][0] += __builtin_bit_cast(float, bf[c][0] ^ af[R & 7][0]);
+                else acc[R][c] = Mfma<T>::run(bf[c], af[R & 7], acc[R][c]);
+            }
             // batch t+2 rides between the MFMAs, one request per row tile (eight waves issuing a whole batch at once
             // behind barrier (A) queue on the texture path and stall in order: 108.7 -> 99.9 us per 256-row block).
             // SPLIT (bf16 256-row blocks, whose multiply stage is 3x longer): the PH activation pieces on every
