@@ -307,9 +307,10 @@ int plan_fastm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, f
 
 // Persistent MFMA decode kernel (qgemm_persistm.h, round 6): 4 bits, M <= 16, K a multiple of 128 (>= 1024), group size 64 / 128.  A set =
 // ng column groups (16 columns each); the sets are dealt round-robin to `grid` workgroups, `visits` sets each (the last round may be short);
-// grid = the fewest workgroups that keep `visits` whole rounds.  ng (override slabs_per_wave) by the model below; visits by override m_tiles.
-// Model (us): 3.3 fixed + the larger of the weights at the HBM rate the decode kernels reach (5.3 TB/s, scaled by the busiest workgroup's
-// share) and what the busiest workgroup pulls through its CU - its sets' weights + once per set the activations (4 ceil(M / 4) rows) - at 60 GB/s.
+// grid = the fewest workgroups that keep `visits` whole rounds.  ng (override slabs_per_wave) by the model below (ties: the smaller); visits by override m_tiles.
+// Model (us; fitted to profiles/r06/call31_persistm_xr.log): the kernel is bound by a wave's in-order issue, not by HBM - a macro-step (128 k
+// of ng groups) costs a wave 0.45 / 0.9 / 1.3 us for ng = 1 / 2 / 3 plus 0.04 / 0.135 / 0.35 us for its 1 / 2 / 4 activation requests, the
+// busiest workgroup runs `visits` sets of ceil(K / 1024) macro-steps; never below the weights at 5.3 TB/s; 3.5 us fixed.
 double persistm_model_us(int M, int N, int K, int num_sms, int ng, int* grid_out, int* visits_out, int visits_ovr) {
     const int groups = N / 16;
     const int nsets = ceil_div(groups, ng);
@@ -317,12 +318,13 @@ double persistm_model_us(int M, int N, int K, int num_sms, int ng, int* grid_out
     if (visits_ovr >= 1) visits = visits_ovr;
     int grid = ceil_div(nsets, visits);
     if (grid > num_sms) { grid = num_sms; visits = ceil_div(nsets, grid); }
-    const double w_set = 8.0 * ng * K, x_set = 8.0 * ((M + 3) / 4) * K;
-    const double hbm = ((double)N * K / 2) / 5.3e6 * ((double)visits * grid * ng / groups) * ((double)num_sms / grid > 1.0 ? 1.0 : 1.0);
-    const double fill = visits * (w_set + x_set) / 60e3;
+    static const double a_ng[4] = {0, 0.45, 0.9, 1.3};
+    const double b_x = M <= 4 ? 0.04 : (M <= 8 ? 0.135 : 0.35);
+    const double issue = (double)visits * ceil_div(K, 1024) * (a_ng[ng] + b_x);
+    const double hbm = ((double)N * K / 2) / 5.3e6;
     if (grid_out) *grid_out = grid;
     if (visits_out) *visits_out = visits;
-    return 3.3 + (hbm > fill ? hbm : fill);
+    return 3.5 + (hbm > issue ? hbm : issue);
 }
 int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, int visits_ovr, flute_plan* p, OneArgs* oa) {
     // (group size 128: a column's scale row must be a whole number of dwords - the macro-step's 4-B scale request)
@@ -333,7 +335,7 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     double best = 0;
     for (int c = 1; c <= 3; ++c) {
         const double us = persistm_model_us(M, N, K, num_sms, c, nullptr, nullptr, visits_ovr);
-        if (c == 1 || us < best) { best = us; ng = c; }
+        if (c == 1 || us < best * 0.98) { best = us; ng = c; }
     }
     if (ng_ovr >= 1 && ng_ovr <= 3) ng = ng_ovr;
     (void)persistm_model_us(M, N, K, num_sms, ng, &grid, &visits, visits_ovr);
@@ -703,7 +705,25 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     const bool fastm_auto = ov.family < 0 && bits == 4 && M >= 5 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 &&
                             (K == 4096 || K == 2048) && fm_wgs <= (long)num_sms && fm_wgs * 2 >= (long)num_sms &&
                             ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0;
+    // Persistent MFMA decode kernel (qgemm_persistm.h, round 6): by override (family 8), or automatically - under the ids that leave the choice
+    // to the planner, as the lean MFMA decode kernel - for 3 <= M <= 16 rows of a 4-bit layer with K >= 6144 (group size 64 / 128); above
+    // M = 8 only while the busiest workgroup's activations (visits x 16 rows x K) stay within 512 KB.  Measured (profiles/r06/call31_persistm_xr.log,
+    // us, table's plan -> this): M = 4: 8192 x 28672 [N x K] 34.6 -> 29.4, 10240 x 8192 20.6 -> 14.3, 4096 x 11008 14.7 -> 9.2, 3584 x 14336 14.6 -> 10.0,
+    // 4096 x 14336 14.7 -> 10.5, 8192^2 12.9 -> 11.7, 28672 x 8192 33.0 -> 31.1; M = 16: 10240 x 8192 22.2 -> 17.4, 4096 x 11008 14.9 -> 11.9,
+    // 8192^2 15.8 -> 13.9; not taken: K = 4096 (14336 x 4096: 11.1 against 11.5 .. 12.4; the lean MFMA decode kernel's and the skinny kernel's
+    // layers), M > 8 on 28672 x 8192 / 8192 x 28672 (39.2 against 36.7, 38.8 against 38.4)
     if (ov.family == kFamilyPersistM) return plan_persistm(bits, lg, M, N, K, num_sms, ov.slabs, ov.m_tiles, p, oa);
+    if (ov.family < 0 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 && K >= 6144 && (lg == 6 || lg == 7) &&
+        (size_t)N * K > ((size_t)16 << 20) && (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip)
+        ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0 && ov.one_shot < 0 && ov.depth <= 0) {
+        flute_plan pm;
+        OneArgs pm_oa;
+        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, &pm, &pm_oa) == FLUTE_OK && (M <= 8 || (long)pm.visits * K <= 16384)) {
+            *p = pm;
+            if (oa) *oa = pm_oa;
+            return FLUTE_OK;
+        }
+    }
     if (ov.family == kFamilyFastM || fastm_auto) {
         if (plan_fastm(bits, lg, M, N, K, num_sms, ov.family == kFamilyFastM ? ov.slabs : -1, p, oa) == FLUTE_OK) return FLUTE_OK;
         memset(p, 0, sizeof(*p));

@@ -241,8 +241,10 @@ def test_plan_families_and_invariants():
     assert rc == 0 and p.family == 5 and p.grid == 224
     rc, p = plan(16, 28672, 4096)                            # 448 slabs: the per-wave kernel, two slabs per wave, no lane sharing
     assert rc == 0 and p.family == 2 and (p.m_block, p.m_tiles, p.slabs_per_wave, p.grid) == (1, 1, 2, 224)
-    rc, p = plan(16, 10240, 8192)                            # 160 slabs fill 62 % of the CUs: no lane sharing either
+    rc, p = plan(16, 10240, 8192, ovr=_lib.Overrides(family=2))     # 160 slabs fill 62 % of the CUs: no lane sharing either
     assert rc == 0 and p.family == 2 and (p.m_block, p.slabs_per_wave, p.grid) == (1, 1, 160)
+    rc, p = plan(16, 10240, 8192)                            # (round 6: the persistent MFMA decode kernel - 214 workgroups x one set of three column groups)
+    assert rc == 0 and (p.family, p.slabs_per_wave, p.grid, p.visits) == (8, 3, 214, 1)
     rc, p = plan(16, 4096, 4096)                             # one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
     assert rc == 0 and p.family == 7 and p.grid == 256
     assert _lib.get().flute_qgemm_plan_ex(0, 4, 64, 16, 4096, 4096, 16, 256, 64 << 20, _lib.Overrides(family=2), p) == 0
@@ -328,6 +330,14 @@ def test_plan_invariants_over_random_shapes():
             ng = p.slabs_per_wave                                  # column groups per workgroup (round 6): the fewest that make one round
             assert ng in (1, 2, 3) and p.grid == -(-(N // 16) // ng) and p.grid <= num_sms and (ng == 1 or -(-(N // 16) // (ng - 1)) > num_sms), what
             assert p.waves == 8 and p.lds_bytes == 32768 + 32 * K and p.ring_depth * 128 * 8 == K, what
+        elif p.family == 8:                                       # persistent MFMA decode kernel (qgemm_persistm.h's host contract)
+            assert bits == 4 and 3 <= M <= 16 and K >= 6144 and K % 128 == 0 and g in (64, 128) and (g == 64 or K % 256 == 0) and tid % 4 == 0, what
+            ng, xr = p.slabs_per_wave, p.k_chunks                  # column groups per set, activation requests per macro-step
+            nsets = -(-(N // 16) // ng)
+            assert ng in (1, 2, 3) and xr == (1 if M <= 4 else 2 if M <= 8 else 4) and p.grid <= min(num_sms, nsets) and p.grid * p.visits >= nsets, what
+            assert (p.visits - 1) * p.grid < nsets and (M <= 8 or p.visits * K <= 16384) and N * K > 16 << 20 and (N // 16) * 2 >= num_sms, what
+            dx = 3 if (xr == 4 or (xr == 2 and ng == 3)) else 6
+            assert p.waves == 8 and p.lds_bytes == 32768 + 8 * dx * (xr * 1024 + 256) + 8 * ng * 1024 and N * K // 2 < 2 ** 32, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
@@ -347,7 +357,7 @@ def test_plan_invariants_over_random_shapes():
             assert (K // g) % 8 == 0 and K % 64 == 0 and N % 256 == 0, what
             assert p.m_block != 4 or bits != 3 or p.lds_bytes == 146 * 1024, what
     # the sweep reaches every kernel of the library
-    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 0), (3, 0), (5, 0), (6, 0), (7, 0)):
+    for key in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (2, 0), (3, 0), (5, 0), (6, 0), (7, 0), (8, 0)):
         assert fams.get(key, 0) > 0, (key, fams)
 
 
@@ -431,8 +441,10 @@ def test_round5_planner_rules():
     rc, p = plan(16, 8192, 28672, tid=3)                          # digit 3 at M <= 16: unchanged (the skinny kernel / two slabs per wave)
     assert rc == 0 and p.family in (2, 5)
     # a grid K split instead of more lane sharing on deep layers (K >= 10240: two slices, K >= 12288: four)
-    rc, p = plan(4, 4096, 11008)
+    rc, p = plan(4, 4096, 11008, ovr=_lib.Overrides(family=2))
     assert rc == 0 and (p.family, p.m_block, p.splitk, p.grid) == (2, 2, 2, 256), p.as_dict()
+    rc, p = plan(4, 4096, 11008)                                  # (round 6: the persistent MFMA decode kernel serves it - 9.2 against 14.7 us)
+    assert rc == 0 and (p.family, p.slabs_per_wave, p.grid) == (8, 1, 256), p.as_dict()
     rc, p = plan(48, 3584, 14336)                                 # (round 6: 64 x 64 tiles x 4 slices are faster still - 16.7 against 21.6 us; by override the rule stands)
     assert rc == 0 and (p.family, p.m_tiles, p.kw, p.splitk, p.grid) == (6, 4, 4, 4, 224), p.as_dict()
     rc, p = plan(48, 3584, 14336, ovr=_lib.Overrides(family=2))

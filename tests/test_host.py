@@ -239,3 +239,34 @@ def test_every_key_of_the_shipped_table_resolves_to_a_legal_plan():
         assert p.grid >= 1 and p.block in (64 * w for w in range(1, 17)) and p.lds_bytes <= 160 * 1024 and p.workspace_needed <= 64 << 20, key
         fams[p.family] = fams.get(p.family, 0) + 1
     assert set(fams) >= {0, 2, 3, 5, 6, 7}, fams                   # the table reaches every kernel family
+
+
+def test_persistent_mfma_decode_kernel_activation_ring_layout():
+    """qgemm_persistm.h: the LDS-DMA writes a request lane-linearly, so the swizzle sits in what a lane ASKS for - lane l of request r
+    fetches chunk (l % 16) ^ 4 (l / 16) ^ g(r) of row 4 r + l / 16 - and the fragment read of MFMA row m = 4 r + mm, k-chunk 4 s + kg looks at
+    position 16 mm + 4 (s ^ mm) + (kg ^ g(r)) of request r's KB.  The two agree, and the 16 lanes of every ds_read_b128 lane group
+    (MI355X_MICROARCH.md's LDS table) hit 16 different 16-B slots - also when rows past the requested ones alias them (M <= 4 / 8: the
+    lanes of a group then share addresses, which broadcast)."""
+    g = lambda r: (4 - r) & 3  # noqa: E731
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+    for r in range(4):
+        where = {}
+        for lane in range(64):
+            mm = lane >> 4
+            where[(mm, (lane & 15) ^ (4 * mm) ^ g(r))] = lane
+        assert len(where) == 64
+        for mm in range(4):
+            for s in range(4):
+                for kg in range(4):
+                    assert where[(mm, 4 * s + kg)] == 16 * mm + 4 * (s ^ mm) + (kg ^ g(r))
+    for xr in (1, 2, 4):
+        for s in range(4):
+            for grp in groups:
+                addrs = set()
+                for lane in grp:
+                    i16, kg = lane & 15, lane >> 4
+                    r, mm = (i16 % (4 * xr)) >> 2, i16 & 3
+                    addrs.add(r * 1024 + (16 * mm + 4 * (s ^ mm) + (kg ^ g(r))) * 16)
+                slots = {(a // 16) % 16 for a in addrs}
+                assert len(slots) == len(addrs) and (xr < 4 or len(addrs) == 16), (xr, s, grp)       # distinct addresses never share a slot

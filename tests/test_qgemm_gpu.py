@@ -431,6 +431,59 @@ def test_lean_mfma_decode_kernel(env):
         assert plan["family"] != 7, (M, K, bits, g, plan)
 
 
+def test_persistent_mfma_decode_kernel(env):
+    """The persistent MFMA decode kernel (qgemm_persistm.h, round 6; family 8): workgroups stream column-group sets x all of K, the eight
+    waves of a workgroup take the 128-k macro-steps w, w + 8, ... - every (group size, TileP, dtype), one / two / three column groups per
+    set, one / two / four activation requests per macro-step (M <= 4 / 8 / 16), one and several sets per workgroup (override m_tiles), K
+    that leaves the waves unequal shares (1152 = 9 macro-steps, 1280 = 10, 3584 = 28) and layers whose last set holds fewer groups (N = 5248:
+    328 groups) - against the oracle, one-hot rows bit-exact (tests/kernel.py:30-36), an arbitrary pair codebook included."""
+    from flute_amd import dev
+    d = env.dev
+    cases = [
+        # tile_p, g, dtype, K, N
+        (32, 64, torch.float16, 8192, 1024), (64, 128, torch.bfloat16, 8192, 2048), (32, 64, torch.bfloat16, 1152, 5248),
+        (64, 64, torch.float16, 3584, 1024), (32, 128, torch.float16, 1280, 5248), (32, 64, torch.float16, 11008, 512),
+    ]
+    for (tile_p, g, dtype, K, N) in cases:
+        bits = 4
+        W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 79 + N % 13 + g)
+        tid = template_ids_for(env.fa, bits, tile_p)[0]
+        Qd, Sd, td = Q.to(d), S.to(d), table.to(d)
+        for pair_codebook in (False, True):
+            t2 = table2
+            if pair_codebook:
+                grid = torch.randn(256, 2).to(dtype)
+                t2 = grid.view(16, 16, 2).contiguous().view(torch.float32)
+            What = env.O.dequantize(Q.numpy(), S, t2, bits, g, tile_p).float()
+            for M, ng, vis in [(M, ng, vis) for M in (1, 3, 4, 7, 8, 13, 16) for ng in ((1, 2, 3) if M in (3, 7, 16) else (-1,)) for vis in ((-1, 3) if M in (3, 16) else (-1,))]:
+                ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis)
+                plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
+                nsets = -(-(N // 16) // plan["slabs_per_wave"])
+                assert plan["family"] == 8 and plan["waves"] == 8 and (ng < 0 or plan["slabs_per_wave"] == ng), plan
+                assert plan["grid"] * plan["visits"] >= nsets and plan["grid"] <= nsets and (vis < 0 or plan["visits"] == vis), plan
+                X = (torch.randn(M, K) / 100).to(dtype)
+                out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert out.shape == (M, N)
+                assert rel_err(out, X.float() @ What) < tol_of(dtype), (tile_p, g, dtype, K, N, M, ng, vis, pair_codebook, rel_err(out, X.float() @ What))
+                ks = torch.randint(0, K, (M,))
+                ks[0] = (0, K - 1)[M % 2]
+                E = torch.zeros(M, K, dtype=dtype)
+                E[torch.arange(M), ks] = 1
+                out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
+                assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, ng, vis, pair_codebook)
+    # automatic on the large layers it was measured on (ids that leave the choice to the planner)
+    for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 2), (4, 14336, 4096, 5), (2, 8192, 8192, 0)):
+        plan = dev.get_plan(M, N, K, 4, 64, template_ids_for(env.fa, 4, 32)[0], env.num_sms, torch.float16)
+        assert env.num_sms != 256 or plan["family"] == fam, (M, N, K, plan)
+    # not taken (the override is refused): 17 rows, 2 / 3 bits, 32- / 256-wide groups, K below 1024 or not a multiple of 128, group size 128 with an odd number of groups
+    for (M, K, bits, g) in ((17, 8192, 4, 64), (8, 8192, 2, 64), (8, 8192, 3, 64), (8, 8192, 4, 32), (8, 8192, 4, 256), (8, 512, 4, 64), (8, 4096 + 64, 4, 64), (8, 1152, 4, 128)):
+        try:
+            plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=8))
+        except Exception:  # noqa: BLE001
+            continue
+        assert plan["family"] != 8, (M, K, bits, g, plan)
+
+
 def test_skinny_mfma_kernel(env):
     """The skinny MFMA kernel (qgemm_skinny.h; override family 5, automatic for 4-bit layers at 3 <= M <= 16 whose
     64-column slabs fill the chip in one round): every k-step depth (K = 32 x depth x waves), 4 and 8 waves, both dtypes
