@@ -77,7 +77,7 @@ def get() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.flute_abi_version() != 7:
+        if lib.flute_abi_version() != 8:
             raise ImportError("flute_amd: ABI version mismatch, rebuild libflute_amd.so")
         _lib = lib
     return _lib

@@ -331,11 +331,19 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 7 || K % 128 || (lg == 7 && K % 256) || K < 1024 || N % 16) return FLUTE_ERR_SHAPE;
     if ((size_t)N * K / 2 >= (size_t)0xfffffff0u || (size_t)N * (size_t)(K >> lg) * 2 >= (size_t)0xfffffff0u || (size_t)M * K * 2 >= (size_t)0xfffffff0u)
         return FLUTE_ERR_SHAPE;
+    // Column groups per set (profiles/r06/planner_regret_persistm*.json).  M <= 8: one, unless a wave's stream is long - visits x macro-steps
+    // >= 40 at one group per set (8192 x 28672, 28672 x 8192: two groups 28.4 against 31.1 us, 30.3 against 30.9; 8192^2, 16 macro-steps: one group
+    // 10.9 against 12.5, 10240 x 8192 14.1 against 16.7).  M > 8, where every set pulls 16 rows of activations: by the model.
     int ng = 1, grid = 0, visits = 0;
-    double best = 0;
-    for (int c = 1; c <= 3; ++c) {
-        const double us = persistm_model_us(M, N, K, num_sms, c, nullptr, nullptr, visits_ovr);
-        if (c == 1 || us < best * 0.98) { best = us; ng = c; }
+    if (M <= 8) {
+        const int groups = N / 16;
+        if (groups > num_sms && (long)ceil_div(groups, num_sms) * ceil_div(K, 1024) >= 40) ng = 2;
+    } else {
+        double best = 0;
+        for (int c = 1; c <= 3; ++c) {
+            const double us = persistm_model_us(M, N, K, num_sms, c, nullptr, nullptr, visits_ovr);
+            if (c == 1 || us < best * 0.98) { best = us; ng = c; }
+        }
     }
     if (ng_ovr >= 1 && ng_ovr <= 3) ng = ng_ovr;
     (void)persistm_model_us(M, N, K, num_sms, ng, &grid, &visits, visits_ovr);
@@ -706,19 +714,22 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                             (K == 4096 || K == 2048) && fm_wgs <= (long)num_sms && fm_wgs * 2 >= (long)num_sms &&
                             ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0;
     // Persistent MFMA decode kernel (qgemm_persistm.h, round 6): by override (family 8), or automatically - under the ids that leave the choice
-    // to the planner, as the lean MFMA decode kernel - for 3 <= M <= 16 rows of a 4-bit layer with K >= 6144 (group size 64 / 128); above
-    // M = 8 only while the busiest workgroup's activations (visits x 16 rows x K) stay within 512 KB.  Measured (profiles/r06/call31_persistm_xr.log,
+    // to the planner, as the lean MFMA decode kernel - for 3 <= M <= 16 rows of a 4-bit layer with K >= 6144 (group size 64 / 128).  Measured (profiles/r06/call31_persistm_xr.log,
     // us, table's plan -> this): M = 4: 8192 x 28672 [N x K] 34.6 -> 29.4, 10240 x 8192 20.6 -> 14.3, 4096 x 11008 14.7 -> 9.2, 3584 x 14336 14.6 -> 10.0,
     // 4096 x 14336 14.7 -> 10.5, 8192^2 12.9 -> 11.7, 28672 x 8192 33.0 -> 31.1; M = 16: 10240 x 8192 22.2 -> 17.4, 4096 x 11008 14.9 -> 11.9,
     // 8192^2 15.8 -> 13.9; not taken: K = 4096 (14336 x 4096: 11.1 against 11.5 .. 12.4; the lean MFMA decode kernel's and the skinny kernel's
-    // layers), M > 8 on 28672 x 8192 / 8192 x 28672 (39.2 against 36.7, 38.8 against 38.4)
+    // layers)
     if (ov.family == kFamilyPersistM) return plan_persistm(bits, lg, M, N, K, num_sms, ov.slabs, ov.m_tiles, p, oa);
-    if (ov.family < 0 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 && K >= 6144 && (lg == 6 || lg == 7) &&
+    // (second sweep, profiles/r06/planner_regret_persistm*.json: also K >= 3584 at M <= 4 - 14336 x 3584 13.2 -> 10.3, 11008 x 4096 11.1 -> 9.6,
+    // 6144 x 4096 8.3 -> 7.6 - and at every M <= 16 where K is neither 2048 nor 4096, the lean MFMA decode / skinny kernels' depths -
+    // 14336 x 3584 M = 8 13.2 -> 11.9; and no limit on the activations at M > 8: equal at M = 16 on the 28672-wide / -deep layers, 7 - 15 % faster at M = 11)
+    const bool pm_k = K >= 6144 || (K >= 3584 && (M <= 4 || (K != 4096 && K != 2048)));
+    if (ov.family < 0 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 && pm_k && (lg == 6 || lg == 7) &&
         (size_t)N * K > ((size_t)16 << 20) && (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip)
         ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0 && ov.one_shot < 0 && ov.depth <= 0) {
         flute_plan pm;
         OneArgs pm_oa;
-        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, &pm, &pm_oa) == FLUTE_OK && (M <= 8 || (long)pm.visits * K <= 16384)) {
+        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, &pm, &pm_oa) == FLUTE_OK) {
             *p = pm;
             if (oa) *oa = pm_oa;
             return FLUTE_OK;

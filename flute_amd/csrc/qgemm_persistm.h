@@ -1,6 +1,6 @@
-// Persistent MFMA decode kernel (round 6): 3 <= M <= 16 rows of a 4-bit layer too large for one round of the lean MFMA decode
+// Persistent MFMA decode kernel (round 6): 3 <= M <= 16 rows of a 4-bit layer too large or too deep for one round of the lean MFMA decode
 // kernel (qgemm_fastm.h: K <= 4096, <= 3 x 256 column groups) - the 70B-class layers (8192 x 28672, 28672 x 8192, 8192^2) and the
-// 8B-class MLP (14336 x 4096, 4096 x 14336) at the batch sizes between the dot-product decode kernels and the MFMA tiles.
+// 8B-class MLP (4096 x 14336, 14336 x 3584) at the batch sizes between the dot-product decode kernels and the MFMA tiles.
 //
 // Until this kernel those launches ran on the per-wave MFMA kernel (qgemm_tile.h) or the skinny kernel (qgemm_skinny.h): 34 - 40 us
 // on 8192 x 28672 / 28672 x 8192 at M = 4 .. 16 where M = 1 streams the same weights in 22.5 us (5.5 TB/s) - every MFMA operand
@@ -11,26 +11,33 @@
 // its (set, macro-step) pairs - the requests of a set's first macro-steps are in flight while the previous set is still multiplied:
 //   * weights: one 16-B request per lane, group and macro-step (4 unit rows x 256 contiguous bytes: whole lines, non-temporal),
 //     SIX macro-steps ahead, into a register ring; lane mapping, DPP quad broadcast and v_perm lookup addresses as qgemm_fastm.h;
-//   * activations: the 16 rows x 256 B of a macro-step by four LDS-DMA requests (rows 4 r .. 4 r + 3 x 256 contiguous bytes: whole
-//     lines; rows >= M lie past the descriptor: zeros without a trip to L2), THREE macro-steps ahead, into a wave-private ring of
-//     three 4-KB slots - no VGPRs, no ds_write, no barrier.  The DMA writes lane-linearly, so the swizzle is applied to what a lane
-//     ASKS for: lane l of request r fetches chunk (l % 16) ^ 4 (l / 16) ^ g(r), g = (0, 3, 2, 1), of row 4 r + l / 16, and the
-//     fragment read of MFMA row m = 4 r + mm, k-chunk 4 s + kg finds it at position 16 mm + 4 (s ^ mm) + (kg ^ g(r)) of request r's
-//     KB: the 16 lanes of every ds_read_b128 lane group hit 16 different 16-B slots (tests/test_host.py);
+//   * activations: the rows x 256 B of a macro-step by XR = 1, 2, 4 LDS-DMA requests (rows 4 r .. 4 r + 3 x 256 contiguous bytes: whole
+//     lines; XR = ceil(M / 4) rounded up - the MFMA rows past 4 XR alias the requested ones, their products are never stored; rows
+//     >= M lie past the descriptor: zeros without a trip to L2) into a wave-private ring of XR-KB slots - no VGPRs, no ds_write, no
+//     barrier.  The ring is SIX slots deep, as the weight ring, where the LDS has room (XR <= 2: 48 / 96 KB), three otherwise.  The DMA
+//     writes lane-linearly, so the swizzle is applied to what a lane ASKS for: lane l of request r fetches chunk
+//     (l % 16) ^ 4 (l / 16) ^ g(r), g = (0, 3, 2, 1), of row 4 r + l / 16, and the fragment read of MFMA row m = 4 r + mm, k-chunk
+//     4 s + kg finds it at position 16 mm + 4 (s ^ mm) + (kg ^ g(r)) of request r's KB: the 16 lanes of every ds_read_b128 lane group
+//     hit 16 different 16-B slots (tests/test_host.py);
 //   * group scales: the 2 (g = 64) or 1 (g = 128) groups of a macro-step for the 16 NG columns by ONE 4-B LDS-DMA request per
-//     macro-step (lane = column: [group set][unit][column of the unit]), read back as one ds_read_b128 per group set: the four
-//     columns of the lane's output unit;
-//   * every macro-step issues the same NG + 5 requests (positions past the wave's last pair go through zero-byte descriptors), so
-//     the counted vmcnt waits are compile-time constants;
+//     macro-step (lane = column: [group][unit][column of the unit]), read back as one ds_read_b128 per group: the four columns of
+//     the lane's output unit;
+//   * every macro-step issues the same NG + 1 + XR requests (positions past the wave's last pair go through zero-byte descriptors), so
+//     the counted vmcnt waits are compile-time constants; the cursors of the three request streams are countdowns and additive
+//     offsets in SGPRs (the first version's per-request multiplications and compares were ~170 scalar instructions per macro-step,
+//     more than its VALU work: 34.4 -> 32.7 us on 28672 x 8192);
 //   * a set's end: the waves' 16 x 16 partial tiles meet in LDS (two barriers per set), every wave sums and stores 32 outputs per
 //     group in a fixed order.
-// The activations cross the CU once per set: 4 ceil(M / 4) x 256 B per macro-step against NG x 1 KB of weights - at M = 16 and
-// NG = 2 twice the weight bytes, from L2.
+// What bounds it (ablation builds, profiles/r06/call29_persistm_ablation.log, 28672 x 8192 at M = 4, first version 34.4 us): NOT HBM - with
+// the weights behind a zero-byte descriptor 31.5 us; without lookups / MFMAs 28.5; without activation / scale requests 28.0; the loop and
+// the weight requests alone 11.6.  A wave's in-order stream (2 waves per SIMD: the activation rings fill the LDS) is the bound: ~1 us per
+// macro-step of two groups.  Hence the short activation requests (XR), the deep rings and the SGPR cursors; M = 4: 34.4 -> 31.1.
 // Arithmetic contract: as the decode kernels (include/flute_amd.h): fp32 group scale on the group's partial sum (one-hot rows bit-exact).
 // Reference: qgemm_device's main loop for small M (flute/csrc/qgemm_kernel.hpp:617-712); its Stream-K schedule over tiles
 // (tile_scheduler_utils.hpp:460-481) is the flat (set, macro-step) stream here, its fix-up the in-workgroup reduction.
-// Host contract (api.hip: plan_persistm): num_bits = 4, M <= 16, K % 128 == 0, K >= 1024, group size 64 or 128, N % 16 == 0,
-// N * K / 2 and N * (K / g) * 2 below 2^32 bytes, grid <= sets, LDS = 32 KB table + 96 KB activation rings + 6 KB scale rings + 8 NG KB.
+// Host contract (api.hip: plan_persistm): num_bits = 4, M <= 16, K % 128 == 0, K >= 1024, group size 64 or 128 (128: K % 256 == 0 - a
+// column's scale row is a whole number of dwords), N % 16 == 0, N * K / 2, N * (K / g) * 2 and M * K * 2 below 2^32 bytes, grid <= sets,
+// XR = 1 / 2 / 4 for M <= 4 / 8 / 16, LDS = persistm_lds_bytes(NG, XR): 32 KB table + rings + 8 NG KB of partial tiles.
 #pragma once
 #include "qgemm_block.h"
 #include "qgemm_fastm.h"

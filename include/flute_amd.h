@@ -23,10 +23,12 @@
 extern "C" {
 #endif
 
-/* 7 (round 6): same structs; flute_plan.kw / m_block of family 6 = K parts per workgroup (2 / 4) / row tiles per XCD group, flute_plan.slabs_per_wave
+/* 8 (round 6, late): same structs; family 8 = persistent MFMA decode kernel (qgemm_persistm.h) in flute_plan.family / flute_overrides.family -
+ *    slabs_per_wave = column groups per set (1 .. 3), visits = sets per workgroup (override: m_tiles), k_chunks = activation requests per macro-step
+ * 7 (round 6): same structs; flute_plan.kw / m_block of family 6 = K parts per workgroup (2 / 4) / row tiles per XCD group, flute_plan.slabs_per_wave
  *    of family 7 = column groups per workgroup (1 .. 3), and the overrides of the same names select them; family 6 refuses waves = 8
  * 6 (round 5): flute_plan.one_shot / flute_overrides.one_shot value 4 (lean decode kernel, qgemm_fast.h), flute_debug_timestamp */
-#define FLUTE_AMD_ABI_VERSION 7
+#define FLUTE_AMD_ABI_VERSION 8
 
 enum flute_dtype { FLUTE_F16 = 0, FLUTE_BF16 = 1 };
 
@@ -83,13 +85,18 @@ typedef struct flute_plan {
                             covers the output),
                             7 = lean MFMA decode kernel (qgemm_fastm.h, round 5: 4 bits, 5 <= M <= 16, K in {2048, 4096}, a
                             workgroup = 4 unit rows x all of K, N / 16 workgroups of 8 waves between half a round and one
-                            round of the CUs, 32 KB + 32 copies x 4 KB of LDS = 160 KB; what it cannot take falls back) */
+                            round of the CUs, 32 KB + 32 copies x 4 KB of LDS = 160 KB; what it cannot take falls back),
+                            8 = persistent MFMA decode kernel (qgemm_persistm.h, round 6: 4 bits, 3 <= M <= 16, K % 128 == 0, group size
+                            64 / 128; `grid` workgroups of 8 waves stream `visits` sets of slabs_per_wave column groups (16 columns each) x
+                            all of K, k_chunks = 1 / 2 / 4 activation requests per 128-k macro-step for M <= 4 / 8 / 16; automatic under the
+                            ids that leave the choice to the planner for layers above 16 M weights with K >= 6144, K >= 3584 at M <= 4 or
+                            where K is neither 2048 nor 4096) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit); family 3: block shape
                             (4 / 5: 256- / 128-row blocks; 8 + rt: 3-bit blocks of rt = 1, 2, 4 row tiles); family 6: row tiles of a
                             column tile that run as consecutive blocks of ONE XCD when K is not split (1 = natural order, 2, 4, 8);
-                            family 7: 16 */
+                            families 7, 8: 16 */
     int m_tiles;         /* family 2: 16-row tiles per wave (1/2/4); family 6: row tiles per output tile (8 / 4) */
-    int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2) */
+    int slabs_per_wave;  /* family 2: 16-unit column slabs per wave (1/2); family 7: column groups per workgroup; family 8: per set (1 .. 3) */
     int waves;           /* waves per workgroup (decode: any count up to 16, not only powers of two) */
     int kw;              /* waves of a workgroup sharing one unit (in-workgroup K split); family 6: K parts per workgroup (2 / 4) */
     int splitk;          /* grid-level K split (fp32 slabs in the workspace; see splitk_mode) */
@@ -100,8 +107,8 @@ typedef struct flute_plan {
     size_t workspace_needed;
     int ring_depth;      /* decode: 1-KiB weight pieces in flight per wave (ring kernel 2/4; one-shot kernels: pieces per wave
                             4/8, 3 bits 2/4; persistent one-shot kernel: pieces per segment); skinny MFMA kernel: k-steps per wave */
-    int visits;          /* decode: unit groups the busiest workgroup streams */
-    int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once */
+    int visits;          /* decode: unit groups the busiest workgroup streams; family 8: sets the busiest workgroup streams */
+    int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once; family 8: activation requests per macro-step */
     int one_shot;        /* decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
                             non-persistent workgroups, every request issued by the prologue, ring_depth = pieces per
                             wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
@@ -121,9 +128,11 @@ typedef struct flute_plan {
  *                   row tiles per XCD group of the block order; waves must be 12 or automatic - the variant without loader
  *                   waves was dropped in round 6);
  *                   7 lean MFMA decode kernel (4 bits, 5 <= M <= 16, K in {2048, 4096}; falls back where it does not apply);
+ *                   8 persistent MFMA decode kernel (4 bits, M <= 16, K % 128 == 0, K >= 1024, group size 64 / 128; slabs_per_wave 1 .. 3:
+ *                   column groups per set, m_tiles: sets per workgroup; refused - FLUTE_ERR_SHAPE - where it does not apply);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 1 / 2 per-wave MFMA
- *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 7 are rejected
+ *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 8 are rejected
  *                   (FLUTE_ERR_SHAPE).  m_tiles / waves / kw / splitk / slabs_per_wave given WITHOUT family = 6 belong to the
  *                   per-wave kernel: such a call never takes the split-K block kernel automatically
  *   m_block         decode: rows per pass; MFMA: R (lanes sharing a unit)

@@ -472,7 +472,8 @@ def test_persistent_mfma_decode_kernel(env):
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, ng, vis, pair_codebook)
     # automatic on the large layers it was measured on (ids that leave the choice to the planner)
-    for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 2), (4, 14336, 4096, 5), (2, 8192, 8192, 0)):
+    for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 8), (4, 14336, 4096, 8), (8, 14336, 4096, 5), (8, 14336, 3584, 8),
+                           (16, 4096, 4096, 7), (4, 4096, 4096, 0), (2, 8192, 8192, 0)):
         plan = dev.get_plan(M, N, K, 4, 64, template_ids_for(env.fa, 4, 32)[0], env.num_sms, torch.float16)
         assert env.num_sms != 256 or plan["family"] == fam, (M, N, K, plan)
     # not taken (the override is refused): 17 rows, 2 / 3 bits, 32- / 256-wide groups, K below 1024 or not a multiple of 128, group size 128 with an odd number of groups
