@@ -327,6 +327,8 @@ double persistm_model_us(int M, int N, int K, int num_sms, int ng, int* grid_out
     return 3.5 + (hbm > issue ? hbm : issue);
 }
 int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, int visits_ovr, flute_plan* p, OneArgs* oa) {
+    // (sixteen waves per workgroup - four per SIMD, rings three deep - measured slower than eight on every layer: 28672 x 8192 M = 4 32.1 against
+    // 31.1 us, 8192^2 13.3 against 11.1, profiles/r06/call33_persistm_16_waves_dropped.log; the kernel keeps the template parameter)
     // (group size 128: a column's scale row must be a whole number of dwords - the macro-step's 4-B scale request)
     if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 7 || K % 128 || (lg == 7 && K % 256) || K < 1024 || N % 16) return FLUTE_ERR_SHAPE;
     if ((size_t)N * K / 2 >= (size_t)0xfffffff0u || (size_t)N * (size_t)(K >> lg) * 2 >= (size_t)0xfffffff0u || (size_t)M * K * 2 >= (size_t)0xfffffff0u)
@@ -349,8 +351,8 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     (void)persistm_model_us(M, N, K, num_sms, ng, &grid, &visits, visits_ovr);
     memset(p, 0, sizeof(*p));
     p->family = kFamilyPersistM;
-    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = ng; p->waves = PM_W; p->kw = PM_W; p->splitk = 1; p->k_per_split = K;
-    p->grid = (unsigned)grid; p->block = (unsigned)(PM_W * 64);
+    p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = ng; p->waves = 8; p->kw = 8; p->splitk = 1; p->k_per_split = K;
+    p->grid = (unsigned)grid; p->block = 512u;
     const int xr = M <= 4 ? 1 : (M <= 8 ? 2 : 4);                  // activation requests per macro-step (4 rows each)
     p->lds_bytes = persistm_lds_bytes(ng, xr); p->lut_copies = 32;
     p->ring_depth = PM_DW; p->visits = visits; p->k_chunks = xr; p->one_shot = 0;
@@ -1361,7 +1363,8 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
 
     if (p.family == kFamilyPersistM) {
-        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks) : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks);
+        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves)
+                                       : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);

@@ -1,14 +1,15 @@
 // Explicit instantiations of the persistent MFMA decode kernel (qgemm_persistm.h), num_bits = 4, bf16: TileP x group size (64 / 128) x
-// column groups per set (1, 2, 3) x activation requests per macro-step (1, 2, 4).  Built with -mllvm -amdgpu-kernarg-preload-count=14
+// column groups per set (1, 2, 3) x activation requests per macro-step (1, 2, 4), eight waves per workgroup.
+// (Sixteen waves - four per SIMD, rings three deep - were instantiated and measured: slower on every layer, profiles/r06/call33_persistm_16_waves_dropped.log.)  Built with -mllvm -amdgpu-kernarg-preload-count=14
 // (Makefile): the arguments arrive in SGPRs.
 #include "kernels.h"
 #include "qgemm_persistm.h"
 namespace flute_amd {
-#define FLUTE_PM1(TP, LG, NG, XR) if (tile_p == TP && lg == LG && ng == NG && xr == XR) return (PersistMKernel)qgemm_persistm_kernel<BF16, TP, LG, NG, XR>;
+#define FLUTE_PM1(TP, LG, NG, XR) if (tile_p == TP && lg == LG && ng == NG && xr == XR && waves == 8) return (PersistMKernel)qgemm_persistm_kernel<BF16, TP, LG, NG, XR, 8>;
 #define FLUTE_PM(TP, LG) \
     FLUTE_PM1(TP, LG, 1, 1) FLUTE_PM1(TP, LG, 1, 2) FLUTE_PM1(TP, LG, 1, 4) FLUTE_PM1(TP, LG, 2, 1) FLUTE_PM1(TP, LG, 2, 2) FLUTE_PM1(TP, LG, 2, 4) \
     FLUTE_PM1(TP, LG, 3, 1) FLUTE_PM1(TP, LG, 3, 2) FLUTE_PM1(TP, LG, 3, 4)
-PersistMKernel persistm_kernel_b4_bf16(int tile_p, int lg, int ng, int xr) {
+PersistMKernel persistm_kernel_b4_bf16(int tile_p, int lg, int ng, int xr, int waves) {
     FLUTE_PM(32, 6) FLUTE_PM(32, 7) FLUTE_PM(64, 6) FLUTE_PM(64, 7)
     return nullptr;
 }

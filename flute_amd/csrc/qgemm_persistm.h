@@ -44,12 +44,13 @@
 
 namespace flute_amd {
 
-constexpr int PM_W = 8, PM_DW = 6;
+constexpr int PM_DW = 6;
 // xr = activation requests per macro-step = ceil(M / 4) rounded up to 1, 2, 4 (a request = 4 rows x 256 B); the activation / scale rings
 // are as deep as the weight ring (six macro-steps) where the LDS has room, three deep otherwise
-__host__ __device__ constexpr int persistm_dx(int ng, int xr) { return (xr == 4 || (xr == 2 && ng == 3)) ? 3 : 6; }
-__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr) {
-    return (size_t)32768 + (size_t)PM_W * persistm_dx(ng, xr) * (xr * 1024 + 256) + (size_t)PM_W * ng * 1024;
+// w = waves per workgroup: 8 (16 - four per SIMD, rings three deep, xr <= 2 - compiles and is correct but measured slower: not instantiated)
+__host__ __device__ constexpr int persistm_dx(int ng, int xr, int w = 8) { return (w == 16 || xr == 4 || (xr == 2 && ng == 3)) ? 3 : 6; }
+__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8) {
+    return (size_t)32768 + (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256) + (size_t)w * ng * 1024;
 }
 // the swizzle constant of activation request r (rows 4 r .. 4 r + 3)
 __host__ __device__ constexpr int pm_g(int r) { return (4 - r) & 3; }
@@ -61,12 +62,15 @@ __device__ __forceinline__ void dma4_buf(uint32_t voff, srd_t srd, uint32_t soff
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
-template <typename T, int TILEP, int LG, int NG, int XR>
-__global__ __launch_bounds__(PM_W * 64) void qgemm_persistm_kernel(
+template <typename T, int TILEP, int LG, int NG, int XR, int W = 8>
+__global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int K, int M, int nsets) {
     using NT = Num<T>;
-    constexpr int W = PM_W, DX = persistm_dx(NG, XR), DW = PM_DW, XQ = XR;
+    constexpr int DX = persistm_dx(NG, XR, W), DW = PM_DW, XQ = XR;
+    static_assert(W == 8 || W == 16, "waves per workgroup");
+    static_assert(persistm_lds_bytes(NG, XR, W) <= 160 * 1024, "rings + partial tiles beside the table image");
+    constexpr uint32_t MS_STRIDE = (uint32_t)W * 256u;               // bytes between a wave's consecutive macro-steps in a row
     static_assert(XR == 1 || XR == 2 || XR == 4, "activation requests per macro-step");
     static_assert(LG == 6 || LG == 7, "group size 64 or 128");
     static_assert(NG >= 1 && NG <= 3, "column groups per set");
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(PM_W * 64) void qgemm_persistm_kernel(
     // additive offsets: every quantity below is wave-uniform and lives in SGPRs (the first version's multiplications and comparisons per
     // request were ~170 scalar instructions per macro-step, more than the VALU work) ----
     const uint32_t set_units = (uint32_t)grid * (4 * NG);           // unit rows between a workgroup's consecutive sets
-    const uint32_t w_jump = set_units * row2k - (uint32_t)n_w * 2048u;      // from a set's last macro-step to the next set's first
+    const uint32_t w_jump = set_units * row2k - (uint32_t)n_w * MS_STRIDE;      // from a set's last macro-step to the next set's first
     uint32_t w_so = (uint32_t)(bid * (4 * NG)) * row2k + (uint32_t)wave * 256u;
     int w_left = n_w, w_u0 = bid * (4 * NG);
     auto groups_at = [&](int u0, int sets_left) { const int gl = (nunits - u0) >> 2; return sets_left > 0 ? (gl < NG ? gl : NG) : 0; };
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(PM_W * 64) void qgemm_persistm_kernel(
             const uint32_t vo = q_vo;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(d), "s"(so) : "memory");
         });
-        w_so += 2048u;
+        w_so += MS_STRIDE;
         if (--w_left == 0) { w_left = n_w; w_so += w_jump; w_u0 += (int)set_units; --w_sets; w_ng = groups_at(w_u0, w_sets); }
     };
     auto request_sx = [&](auto slot_tag) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(PM_W * 64) void qgemm_persistm_kernel(
             if constexpr (NXR >= 2) dma16_buf(v1, dx, x_so, l_x + 1024u);
             if constexpr (NXR == 4) { dma16_buf(v2, dx, x_so, l_x + 2048u); dma16_buf(v3, dx, x_so, l_x + 3072u); }
         }
-        x_so += 2048u;
+        x_so += MS_STRIDE;
         if (--x_left == 0) {                                       // (wave-uniform) the next set's columns
             x_left = n_w; x_so = (uint32_t)wave * 256u; --x_sets; x_set += grid;
             s_vo = scale_voff(x_set);

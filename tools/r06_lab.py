@@ -114,8 +114,8 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
                 E = torch.zeros(M, K, device=d, dtype=dtype)
                 E[torch.arange(M, device=d), ks] = 1
                 for ng in (1, 2, 3):
-                    for vis in (-1, 1, 3):
-                        ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis)
+                    for vis in (-1, 1, 3, -16):
+                        ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis) if vis != -16 else dev.Overrides(family=8, slabs_per_wave=ng, waves=8)
                         try:
                             pl = dev.get_plan(M, N, K, 4, g, tid, L.num_sms, dtype, ovr)
                         except Exception as e:  # noqa: BLE001
@@ -138,7 +138,7 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
         for M in (4, 8, 16):
             L.time_one(M, N, K, 4, f16, None, steps=200, tag="tuned table")
             for ng in (1, 2, 3):
-                L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng), steps=200, tag=f"persistm ng={ng}")
+                L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng, waves=8), steps=200, tag=f"persistm ng={ng}")
 elif case == "persistm_abl":   # ablation builds of the persistent MFMA decode kernel (-DFLUTE_PM_ABLATE=N)
     for (N, K, ng) in ((28672, 8192, 2), (8192, 28672, 2), (4096, 14336, 1)):
         for M in (4, 16):
