@@ -49,8 +49,11 @@ constexpr int PM_DW = 6;
 // are as deep as the weight ring (six macro-steps) where the LDS has room, three deep otherwise
 // w = waves per workgroup: 8 (16 - four per SIMD, rings three deep, xr <= 2 - compiles and is correct but measured slower: not instantiated)
 __host__ __device__ constexpr int persistm_dx(int ng, int xr, int w = 8) { return (w == 16 || xr == 4 || (xr == 2 && ng == 3)) ? 3 : 6; }
+// M <= 4 (xr = 1): the table image at a 256-B entry stride (64 KB, the upper half of every entry unused) - the v_perm that extracts a lane's
+// byte then IS the lookup address, no shift: one VALU instruction less per pair
+__host__ __device__ constexpr size_t persistm_table_bytes(int xr) { return xr == 1 ? 65536 : 32768; }
 __host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8) {
-    return (size_t)32768 + (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256) + (size_t)w * ng * 1024;
+    return persistm_table_bytes(xr) + (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256) + (size_t)w * ng * 1024;
 }
 // the swizzle constant of activation request r (rows 4 r .. 4 r + 3)
 __host__ __device__ constexpr int pm_g(int r) { return (4 - r) & 3; }
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     constexpr int NXR = (dbg & 16) ? 0 : XQ, NSR = (dbg & 32) ? 0 : 1;
     constexpr int NREQ = NG + NSR + NXR;                            // requests per macro-step: weights, scales, activations
     constexpr uint32_t XSLOT = (uint32_t)XR * 1024u;
-    constexpr uint32_t X_BASE = 32768u, XREG = (uint32_t)DX * XSLOT;
+    constexpr bool WIDE = XR == 1;                                  // table image at a 256-B entry stride
+    constexpr uint32_t X_BASE = (uint32_t)persistm_table_bytes(XR), XREG = (uint32_t)DX * XSLOT;
     constexpr uint32_t S_BASE = X_BASE + (uint32_t)W * XREG, SREG = (uint32_t)DX * 256u;
     constexpr uint32_t R_BASE = S_BASE + (uint32_t)W * SREG;
     constexpr int ENT = 256 / W, RUNS = 32 / W;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     });
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- table image: entry e at [128 e, 128 e + 128): a wave writes RUNS runs of 8 entries (1 KiB, lane-linear) ----
+    // ---- table image: entry e at [128 e, 128 e + 128) (WIDE: [256 e, 256 e + 128)): a wave writes RUNS runs of 8 entries (1 KiB, lane-linear) ----
     vm_wait_regs<DW * NG + DX * (NSR + NXR)>(lut_v);
     {
         uint32_t te[RUNS];
@@ -219,13 +223,14 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
         for (int u = 0; u < RUNS; ++u) te[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((u * 8 + (lane >> 3)) * 4, (int)lut_v);
 #pragma unroll
         for (int u = 0; u < RUNS; ++u)
-            *reinterpret_cast<uint4*>(smem + (uint32_t)(wave * RUNS + u) * 1024u + (uint32_t)lane * 16u) = make_uint4(te[u], te[u], te[u], te[u]);
+            *reinterpret_cast<uint4*>(smem + (WIDE ? (uint32_t)((wave * RUNS + u) * 8 + (lane >> 3)) * 256u + (uint32_t)(lane & 7) * 16u
+                                                   : (uint32_t)(wave * RUNS + u) * 1024u + (uint32_t)lane * 16u)) = make_uint4(te[u], te[u], te[u], te[u]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // the table image is complete
 
     // ---- per-lane LDS addresses ----
-    const uint32_t lane_off2 = (uint32_t)(lane & 31) * 8u;          // twice the copy offset (the address is halved after the v_perm)
+    const uint32_t lane_off2 = (uint32_t)(lane & 31) * (WIDE ? 4u : 8u);     // twice the copy offset (the address is halved after the v_perm); WIDE: the offset itself
     const uint32_t sel = 0x0c0c0400u | ((uint32_t)ju << 8);         // {copy offset x 2, byte ju of the word, 0, 0}
     // activation fragment of step s: row i16 = 4 r + mm, chunk 4 s + kg -> request r's KB, position 16 mm + 4 (s ^ mm) + (kg ^ g(r))
     uint32_t xa[4];
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t wsrc = (uint32_t)__builtin_amdgcn_mov_dpp((int)q[qs][g][c], s * 0x55, 0xF, 0xF, true);       // quad_perm [s, s, s, s]
-                ad[c] = __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
+                ad[c] = WIDE ? __builtin_amdgcn_perm(wsrc, lane_off2, sel) : __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
             }
             asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]));
 #pragma unroll

@@ -340,7 +340,7 @@ def test_plan_invariants_over_random_shapes():
             assert ng in (1, 2, 3) and xr == (1 if M <= 4 else 2 if M <= 8 else 4) and p.grid <= min(num_sms, nsets) and p.grid * p.visits >= nsets, what
             assert (p.visits - 1) * p.grid < nsets and N * K > 16 << 20 and (N // 16) * 2 >= num_sms, what
             dx = 3 if (xr == 4 or (xr == 2 and ng == 3)) else 6
-            assert p.waves == 8 and p.lds_bytes == 32768 + 8 * dx * (xr * 1024 + 256) + 8 * ng * 1024 and N * K // 2 < 2 ** 32, what
+            assert p.waves == 8 and p.lds_bytes == (65536 if xr == 1 else 32768) + 8 * dx * (xr * 1024 + 256) + 8 * ng * 1024 and N * K // 2 < 2 ** 32, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what
