@@ -529,7 +529,11 @@ def main():
                 ("W3G64 bf16 M=1 K=8192 N=28672 (configs[2])", 1, 28672, 8192, 3, bf16, 0),
                 ("W4G64 fp16 M=1 K=8192 N=28672 full layer", 1, 28672, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=2 K=8192 N=28672 (two rows: persistent one-shot kernel)", 2, 28672, 8192, 4, dtype, 0),
-                ("W4G64 fp16 M=16 K=8192 N=28672 (per-wave MFMA kernel, two slabs per wave)", 16, 28672, 8192, 4, dtype, 0),
+                ("W4G64 fp16 M=4 K=8192 N=28672 (persistent MFMA decode kernel)", 4, 28672, 8192, 4, dtype, 0),
+                ("W4G64 fp16 M=4 K=28672 N=8192 (persistent MFMA decode kernel)", 4, 8192, 28672, 4, dtype, 0),
+                ("W4G64 fp16 M=8 K=28672 N=8192 (persistent MFMA decode kernel)", 8, 8192, 28672, 4, dtype, 0),
+                ("W4G64 fp16 M=4 K=14336 N=4096 (persistent MFMA decode kernel)", 4, 4096, 14336, 4, dtype, 0),
+                ("W4G64 fp16 M=16 K=8192 N=28672 (persistent MFMA decode kernel)", 16, 28672, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=64 K=8192 N=28672 (per-wave MFMA kernel, two slabs per wave)", 64, 28672, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=1 K=8192 N=3584 = TP-8 column shard of 8192x28672 (configs[3])", 1, 3584, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=1 K=3584 N=4096 pair codebook + hadamard_size=512 (configs[4], Gemma-2-9B)", 1, 4096, 3584, 4, dtype, 512)):
