@@ -277,6 +277,9 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
             }
         }
     };
+    // (Measured and dropped, profiles/r06/call35_persistm_two_step_lookahead_dropped.log: the LDS reads TWO steps ahead of their MFMA at one group per
+    // set - three buffers, one lgkmcnt counting two steps' reads: equal within the noise, 29.5 against 30.1 us on 28672 x 8192, 30.4 against 29.2 on
+    // 8192 x 28672 - the LDS latency is not what a wave waits for.)
     // step s's reads have returned once at most Y younger LDS operations are outstanding
     auto wait_step = [&](auto s_tag, auto younger_tag) {
         constexpr int s = decltype(s_tag)::value, Y = decltype(younger_tag)::value;

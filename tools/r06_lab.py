@@ -140,7 +140,7 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
             for ng in (1, 2, 3):
                 L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng, waves=8), steps=200, tag=f"persistm ng={ng}")
 elif case == "persistm_abl":   # ablation builds of the persistent MFMA decode kernel (-DFLUTE_PM_ABLATE=N)
-    for (N, K, ng) in ((28672, 8192, 2), (8192, 28672, 2), (4096, 14336, 1)):
+    for (N, K, ng) in ((28672, 8192, 1), (8192, 28672, 2), (4096, 14336, 1)):
         for M in (4, 16):
             L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng), steps=200, tag=tag)
 elif case == "m256x":     # M = 256 on 4096^2 and its neighbours: XCD group size and request distance
