@@ -326,7 +326,7 @@ double persistm_model_us(int M, int N, int K, int num_sms, int ng, int* grid_out
     if (visits_out) *visits_out = visits;
     return 3.5 + (hbm > issue ? hbm : issue);
 }
-int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, int visits_ovr, flute_plan* p, OneArgs* oa) {
+int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr, int visits_ovr, int xres_ovr, flute_plan* p, OneArgs* oa) {
     // (sixteen waves per workgroup - four per SIMD, rings three deep - measured slower than eight on every layer: 28672 x 8192 M = 4 32.1 against
     // 31.1 us, 8192^2 13.3 against 11.1, profiles/r06/call33_persistm_16_waves_dropped.log; the kernel keeps the template parameter)
     // (group size 128: a column's scale row must be a whole number of dwords - the macro-step's 4-B scale request)
@@ -354,8 +354,11 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     p->m_block = 16; p->m_tiles = 1; p->slabs_per_wave = ng; p->waves = 8; p->kw = 8; p->splitk = 1; p->k_per_split = K;
     p->grid = (unsigned)grid; p->block = 512u;
     const int xr = M <= 4 ? 1 : (M <= 8 ? 2 : 4);                  // activation requests per macro-step (4 rows each)
-    p->lds_bytes = persistm_lds_bytes(ng, xr); p->lut_copies = 32;
-    p->ring_depth = PM_DW; p->visits = visits; p->k_chunks = xr; p->one_shot = 0;
+    // activations resident in LDS (staged once per workgroup, no activation request in the loop) where 4 xr rows x K fit in 64 KB beside the rest;
+    // override one_shot = 0 keeps the rings
+    const bool xres = (long)K * xr <= 8192 && xr <= 2 && !(xr == 1 && ng == 3) && xres_ovr != 0;
+    p->lds_bytes = persistm_lds_bytes(ng, xr, 8, xres); p->lut_copies = 32;
+    p->ring_depth = PM_DW; p->visits = visits; p->k_chunks = xr; p->one_shot = xres ? 1 : 0;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = PM_DW; }
     return FLUTE_OK;
 }
@@ -721,17 +724,19 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // 4096 x 14336 14.7 -> 10.5, 8192^2 12.9 -> 11.7, 28672 x 8192 33.0 -> 31.1; M = 16: 10240 x 8192 22.2 -> 17.4, 4096 x 11008 14.9 -> 11.9,
     // 8192^2 15.8 -> 13.9; not taken: K = 4096 (14336 x 4096: 11.1 against 11.5 .. 12.4; the lean MFMA decode kernel's and the skinny kernel's
     // layers)
-    if (ov.family == kFamilyPersistM) return plan_persistm(bits, lg, M, N, K, num_sms, ov.slabs, ov.m_tiles, p, oa);
+    if (ov.family == kFamilyPersistM) return plan_persistm(bits, lg, M, N, K, num_sms, ov.slabs, ov.m_tiles, ov.one_shot, p, oa);
     // (second sweep, profiles/r06/planner_regret_persistm*.json: also K >= 3584 at M <= 4 - 14336 x 3584 13.2 -> 10.3, 11008 x 4096 11.1 -> 9.6,
     // 6144 x 4096 8.3 -> 7.6 - and at every M <= 16 where K is neither 2048 nor 4096, the lean MFMA decode / skinny kernels' depths -
     // 14336 x 3584 M = 8 13.2 -> 11.9; and no limit on the activations at M > 8: equal at M = 16 on the 28672-wide / -deep layers, 7 - 15 % faster at M = 11)
-    const bool pm_k = K >= 6144 || (K >= 3584 && (M <= 4 || (K != 4096 && K != 2048)));
+    // (third step, profiles/r06/call37_persistm_resident_activations.log: with the activations RESIDENT in LDS - K * ceil(M / 4) rows within 64 KB - also
+    // K = 4096 at M <= 8: 4096^2 M = 8 5.9 -> 5.5, 11008 x 4096 10.9 -> 9.3, 14336 x 4096 11.4 -> 11.3)
+    const bool pm_k = K >= 6144 || (K >= 3584 && (M <= 8 || (K != 4096 && K != 2048)));
     if (ov.family < 0 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 && pm_k && (lg == 6 || lg == 7) &&
-        (size_t)N * K > ((size_t)16 << 20) && (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip)
+        (size_t)N * K + (M >= 5 ? 1 : 0) > ((size_t)16 << 20) && (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip; 4096^2 itself from M = 5)
         ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0 && ov.one_shot < 0 && ov.depth <= 0) {
         flute_plan pm;
         OneArgs pm_oa;
-        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, &pm, &pm_oa) == FLUTE_OK) {
+        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, -1, &pm, &pm_oa) == FLUTE_OK) {
             *p = pm;
             if (oa) *oa = pm_oa;
             return FLUTE_OK;
@@ -1363,8 +1368,8 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
 
     if (p.family == kFamilyPersistM) {
-        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves)
-                                       : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves);
+        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot)
+                                       : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot);
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);

@@ -5,11 +5,14 @@
 #include "kernels.h"
 #include "qgemm_persistm.h"
 namespace flute_amd {
-#define FLUTE_PM1(TP, LG, NG, XR) if (tile_p == TP && lg == LG && ng == NG && xr == XR && waves == 8) return (PersistMKernel)qgemm_persistm_kernel<F16, TP, LG, NG, XR, 8>;
+#define FLUTE_PM1(TP, LG, NG, XR) if (tile_p == TP && lg == LG && ng == NG && xr == XR && waves == 8 && !xres) return (PersistMKernel)qgemm_persistm_kernel<F16, TP, LG, NG, XR, 8>;
+// activations resident in LDS (K * xr <= 8192)
+#define FLUTE_PMR(TP, LG, NG, XR) if (tile_p == TP && lg == LG && ng == NG && xr == XR && waves == 8 && xres) return (PersistMKernel)qgemm_persistm_kernel<F16, TP, LG, NG, XR, 8, true>;
 #define FLUTE_PM(TP, LG) \
     FLUTE_PM1(TP, LG, 1, 1) FLUTE_PM1(TP, LG, 1, 2) FLUTE_PM1(TP, LG, 1, 4) FLUTE_PM1(TP, LG, 2, 1) FLUTE_PM1(TP, LG, 2, 2) FLUTE_PM1(TP, LG, 2, 4) \
-    FLUTE_PM1(TP, LG, 3, 1) FLUTE_PM1(TP, LG, 3, 2) FLUTE_PM1(TP, LG, 3, 4)
-PersistMKernel persistm_kernel_b4_f16(int tile_p, int lg, int ng, int xr, int waves) {
+    FLUTE_PM1(TP, LG, 3, 1) FLUTE_PM1(TP, LG, 3, 2) FLUTE_PM1(TP, LG, 3, 4) \
+    FLUTE_PMR(TP, LG, 1, 1) FLUTE_PMR(TP, LG, 2, 1) FLUTE_PMR(TP, LG, 1, 2) FLUTE_PMR(TP, LG, 2, 2) FLUTE_PMR(TP, LG, 3, 2)
+PersistMKernel persistm_kernel_b4_f16(int tile_p, int lg, int ng, int xr, int waves, int xres) {
     FLUTE_PM(32, 6) FLUTE_PM(32, 7) FLUTE_PM(64, 6) FLUTE_PM(64, 7)
     return nullptr;
 }

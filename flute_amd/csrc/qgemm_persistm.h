@@ -48,12 +48,14 @@ constexpr int PM_DW = 6;
 // xr = activation requests per macro-step = ceil(M / 4) rounded up to 1, 2, 4 (a request = 4 rows x 256 B); the activation / scale rings
 // are as deep as the weight ring (six macro-steps) where the LDS has room, three deep otherwise
 // w = waves per workgroup: 8 (16 - four per SIMD, rings three deep, xr <= 2 - compiles and is correct but measured slower: not instantiated)
-__host__ __device__ constexpr int persistm_dx(int ng, int xr, int w = 8) { return (w == 16 || xr == 4 || (xr == 2 && ng == 3)) ? 3 : 6; }
+// xres (round 6, last step): the activations RESIDENT in LDS - all 4 xr rows x K staged once per workgroup (<= 64 KB: K <= 8192 / xr), no activation
+// request in the loop, the scale ring six deep
+__host__ __device__ constexpr int persistm_dx(int ng, int xr, int w = 8, bool xres = false) { return (!xres && (w == 16 || xr == 4 || (xr == 2 && ng == 3))) ? 3 : 6; }
 // M <= 4 (xr = 1): the table image at a 256-B entry stride (64 KB, the upper half of every entry unused) - the v_perm that extracts a lane's
 // byte then IS the lookup address, no shift: one VALU instruction less per pair
 __host__ __device__ constexpr size_t persistm_table_bytes(int xr) { return xr == 1 ? 65536 : 32768; }
-__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8) {
-    return persistm_table_bytes(xr) + (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256) + (size_t)w * ng * 1024;
+__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8, bool xres = false) {
+    return persistm_table_bytes(xr) + (xres ? (size_t)65536 + (size_t)w * 6 * 256 : (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256)) + (size_t)w * ng * 1024;
 }
 // the swizzle constant of activation request r (rows 4 r .. 4 r + 3)
 __host__ __device__ constexpr int pm_g(int r) { return (4 - r) & 3; }
@@ -65,14 +67,14 @@ __device__ __forceinline__ void dma4_buf(uint32_t voff, srd_t srd, uint32_t soff
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
-template <typename T, int TILEP, int LG, int NG, int XR, int W = 8>
+template <typename T, int TILEP, int LG, int NG, int XR, int W = 8, bool XRES = false>
 __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int K, int M, int nsets) {
     using NT = Num<T>;
-    constexpr int DX = persistm_dx(NG, XR, W), DW = PM_DW, XQ = XR;
+    constexpr int DX = persistm_dx(NG, XR, W, XRES), DW = PM_DW, XQ = XR;
     static_assert(W == 8 || W == 16, "waves per workgroup");
-    static_assert(persistm_lds_bytes(NG, XR, W) <= 160 * 1024, "rings + partial tiles beside the table image");
+    static_assert(persistm_lds_bytes(NG, XR, W, XRES) <= 160 * 1024, "rings + partial tiles beside the table image");
     constexpr uint32_t MS_STRIDE = (uint32_t)W * 256u;               // bytes between a wave's consecutive macro-steps in a row
     static_assert(XR == 1 || XR == 2 || XR == 4, "activation requests per macro-step");
     static_assert(LG == 6 || LG == 7, "group size 64 or 128");
@@ -84,11 +86,11 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
 #else
     constexpr int dbg = 0;
 #endif
-    constexpr int NXR = (dbg & 16) ? 0 : XQ, NSR = (dbg & 32) ? 0 : 1;
+    constexpr int NXR = ((dbg & 16) || XRES) ? 0 : XQ, NSR = (dbg & 32) ? 0 : 1;
     constexpr int NREQ = NG + NSR + NXR;                            // requests per macro-step: weights, scales, activations
     constexpr uint32_t XSLOT = (uint32_t)XR * 1024u;
     constexpr bool WIDE = XR == 1;                                  // table image at a 256-B entry stride
-    constexpr uint32_t X_BASE = (uint32_t)persistm_table_bytes(XR), XREG = (uint32_t)DX * XSLOT;
+    constexpr uint32_t X_BASE = (uint32_t)persistm_table_bytes(XR), XREG = XRES ? 65536u / W : (uint32_t)DX * XSLOT;
     constexpr uint32_t S_BASE = X_BASE + (uint32_t)W * XREG, SREG = (uint32_t)DX * 256u;
     constexpr uint32_t R_BASE = S_BASE + (uint32_t)W * SREG;
     constexpr int ENT = 256 / W, RUNS = 32 / W;
@@ -111,6 +113,16 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const uint32_t row2k = (uint32_t)K * 2u;                        // bytes of a unit row = of an activation row
 
     const srd_t lut_srd = make_srd(QM2, 1024u);
+    if constexpr (XRES) {
+        // resident activations: macro-step ms of rows 4 r .. 4 r + 3 at X_BASE + ms * XSLOT + r KB (the rings' layout, indexed by the macro-step); the
+        // waves share the requests, which are the launch's oldest: every counted wait below covers them, the prologue's barrier publishes them
+        const srd_t xs0 = make_srd(Ap, (uint32_t)M * (uint32_t)K * 2u);
+        for (int ms = wave; ms < (K >> 7); ms += W)
+#pragma unroll
+            for (int r = 0; r < XR; ++r)
+                dma16_buf((uint32_t)(4 * r + (lane >> 4)) * (uint32_t)K * 2u + (uint32_t)((lane & 15) ^ (4 * (lane >> 4)) ^ pm_g(r)) * 16u, xs0, (uint32_t)ms * 256u,
+                          X_BASE + (uint32_t)ms * XSLOT + (uint32_t)r * 1024u);
+    }
     uint32_t lut_v = buf_load4((uint32_t)(wave * ENT + (lane & (ENT - 1))) * 4u, lut_srd);
     const srd_t q_srd = make_srd(Qp, (uint32_t)((size_t)nunits * row2k));
     const srd_t x_srd = make_srd(Ap, (uint32_t)M * row2k);
@@ -144,6 +156,9 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     int x_left = n_w, x_sets = n_items, x_set = bid;
     uint32_t s_vo = scale_voff(bid);
     int c_left = n_w, c_set = bid;
+    // XRES: LDS offset of the macro-step whose steps 1 .. 3 are being issued / of the next pair's macro-step (whose step 0 is issued at step 3)
+    uint32_t xo_cur = (uint32_t)wave * XSLOT, xo_nxt = n_w > 1 ? (uint32_t)(wave + W) * XSLOT : (uint32_t)wave * XSLOT;
+    int xo_left = n_w > 1 ? n_w - 1 : n_w;                          // macro-steps from xo_nxt's to its set's end, itself included
 
     ring16_t q[DW][NG];
     auto request_w = [&](auto slot_tag) {
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
         // (rows past the requested 4 XR alias the requested ones: their products are never stored)
         const int r = (i16 % (4 * XR)) >> 2, mm = i16 & 3;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xa[s] = xreg + (uint32_t)r * 1024u + (uint32_t)(16 * mm + 4 * (s ^ mm) + (kg ^ pm_g(r))) * 16u;
+        for (int s = 0; s < 4; ++s) xa[s] = (XRES ? X_BASE : xreg) + (uint32_t)r * 1024u + (uint32_t)(16 * mm + 4 * (s ^ mm) + (kg ^ pm_g(r))) * 16u;
     }
     const uint32_t sc_a = sreg + (uint32_t)kg * 16u;                // the four columns of the lane's output unit kg: + 64 g
 
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     for (int g = 0; g < NG; ++g) { accf[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; part[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     // the LDS reads of step s of the macro-step in ring slots (qs, xs): 4 NG lookups + the fragment (+ NG scale reads at s = 0)
-    auto issue_step = [&](auto qs_tag, auto s_tag) {
+    auto issue_step = [&](auto qs_tag, auto s_tag, uint32_t xoff = 0u) {       // xoff (XRES): the macro-step's place in the resident activations
         constexpr int qs = decltype(qs_tag)::value, s = decltype(s_tag)::value;
         constexpr int xs = qs % DX;
         if constexpr (!(dbg & 4)) static_for<NG>([&](auto g_tag) {
@@ -266,8 +281,13 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
             for (int c = 0; c < 4; ++c) v[s & 1][g][c] = lds_lookup32(ad[c]);
         });
         ring16_t& dst = xb[s & 1];
-        const uint32_t xaddr = xa[s];
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(xaddr), "n"(xs * (int)XSLOT) : "memory");
+        if constexpr (XRES) {
+            const uint32_t xaddr = xa[s] + xoff;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(xaddr) : "memory");
+        } else {
+            const uint32_t xaddr = xa[s];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(xaddr), "n"(xs * (int)XSLOT) : "memory");
+        }
         if constexpr (s == 0) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -339,7 +359,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     // ---- the flat loop: one body per weight-ring slot; step 3 of a macro-step waits for the next macro-step's data and issues its
     // step-0 reads, the requests of six / three macro-steps ahead follow the last read of the slots they refill ----
     wait_requests(std::integral_constant<int, 0>{}, std::integral_constant<int, (DX - 1) * NREQ>{});
-    issue_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    issue_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, xo_cur);
     auto body = [&](auto qs_tag) {
         constexpr int qs = decltype(qs_tag)::value;
         constexpr int nq = (qs + 1) % DW;
@@ -347,10 +367,10 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
         static_for<4>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             if constexpr (s < 3) {
-                issue_step(qs_tag, std::integral_constant<int, s + 1>{});
+                issue_step(qs_tag, std::integral_constant<int, s + 1>{}, xo_cur);
             } else {
                 wait_requests(nq_t{}, std::integral_constant<int, (DX - 2) * NREQ>{});
-                issue_step(nq_t{}, std::integral_constant<int, 0>{});
+                issue_step(nq_t{}, std::integral_constant<int, 0>{}, xo_nxt);
             }
             wait_step(s_tag, std::integral_constant<int, (s < 3) ? 4 * NG + 1 : (5 * NG + 1 < 15 ? 5 * NG + 1 : 15)>{});   // (lgkmcnt counts to 15)
             if constexpr (s == 0) name_scales(std::integral_constant<int, qs & 1>{});
@@ -376,6 +396,10 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
         request_w(qs_tag);
         request_sx(std::integral_constant<int, qs % DX>{});
         if (--c_left == 0) { c_left = n_w; finish_set(c_set); c_set += grid; }     // (wave-uniform)
+        if constexpr (XRES) {
+            xo_cur = xo_nxt;
+            if (--xo_left == 0) { xo_left = n_w; xo_nxt = (uint32_t)wave * XSLOT; } else xo_nxt += (uint32_t)W * XSLOT;
+        }
     };
     static_assert(DW == 6, "the loop below spells the six bodies out");
     for (int left = P;;) {

@@ -89,7 +89,7 @@ typedef struct flute_plan {
                             8 = persistent MFMA decode kernel (qgemm_persistm.h, round 6: 4 bits, 3 <= M <= 16, K % 128 == 0, group size
                             64 / 128; `grid` workgroups of 8 waves stream `visits` sets of slabs_per_wave column groups (16 columns each) x
                             all of K, k_chunks = 1 / 2 / 4 activation requests per 128-k macro-step for M <= 4 / 8 / 16; automatic under the
-                            ids that leave the choice to the planner for layers above 16 M weights with K >= 6144, K >= 3584 at M <= 4 or
+                            ids that leave the choice to the planner for layers above 16 M weights with K >= 6144, K >= 3584 at M <= 8 or
                             where K is neither 2048 nor 4096) */
     int m_block;         /* decode: rows per pass (1/2/4); family 2: R (lanes sharing a unit); family 3: block shape
                             (4 / 5: 256- / 128-row blocks; 8 + rt: 3-bit blocks of rt = 1, 2, 4 row tiles); family 6: row tiles of a
@@ -109,7 +109,8 @@ typedef struct flute_plan {
                             4/8, 3 bits 2/4; persistent one-shot kernel: pieces per segment); skinny MFMA kernel: k-steps per wave */
     int visits;          /* decode: unit groups the busiest workgroup streams; family 8: sets the busiest workgroup streams */
     int k_chunks;        /* decode: passes over K when the activations do not fit in LDS at once; family 8: activation requests per macro-step */
-    int one_shot;        /* decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
+    int one_shot;        /* family 8: 1 = the activations resident in LDS (4 k_chunks rows x K within 64 KB), 0 = through the wave-private rings;
+                            decode: 0 = persistent ring kernel (qgemm_stream.h); 1 = one-shot kernel (qgemm_oneshot.h:
                             non-persistent workgroups, every request issued by the prologue, ring_depth = pieces per
                             wave), 2 = the same with the software-pipelined piece loop, 3 = persistent one-shot kernel
                             (qgemm_persist.h: table / activations staged once, every wave walks `visits` units of
@@ -129,7 +130,8 @@ typedef struct flute_plan {
  *                   waves was dropped in round 6);
  *                   7 lean MFMA decode kernel (4 bits, 5 <= M <= 16, K in {2048, 4096}; falls back where it does not apply);
  *                   8 persistent MFMA decode kernel (4 bits, M <= 16, K % 128 == 0, K >= 1024, group size 64 / 128; slabs_per_wave 1 .. 3:
- *                   column groups per set, m_tiles: sets per workgroup; refused - FLUTE_ERR_SHAPE - where it does not apply);
+ *                   column groups per set, m_tiles: sets per workgroup, one_shot 0: activation rings also where the activations could be resident;
+ *                   refused - FLUTE_ERR_SHAPE - where it does not apply);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for
  *                   small layers called with a Hadamard size, to keep the rotation fused), 1 / 2 per-wave MFMA
  *                   kernel, 3 block-tiled prefill kernel (m_tiles 8 / 4: 256 / 128-row block); 4 and > 8 are rejected

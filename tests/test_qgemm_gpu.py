@@ -435,8 +435,9 @@ def test_persistent_mfma_decode_kernel(env):
     """The persistent MFMA decode kernel (qgemm_persistm.h, round 6; family 8): workgroups stream column-group sets x all of K, the eight
     waves of a workgroup take the 128-k macro-steps w, w + 8, ... - every (group size, TileP, dtype), one / two / three column groups per
     set, one / two / four activation requests per macro-step (M <= 4 / 8 / 16), one and several sets per workgroup (override m_tiles), K
-    that leaves the waves unequal shares (1152 = 9 macro-steps, 1280 = 10, 3584 = 28) and layers whose last set holds fewer groups (N = 5248:
-    328 groups) - against the oracle, one-hot rows bit-exact (tests/kernel.py:30-36), an arbitrary pair codebook included."""
+    that leaves the waves unequal shares (1152 = 9 macro-steps, 1280 = 10, 3584 = 28), layers whose last set holds fewer groups (N = 5248:
+    328 groups), the activations resident in LDS (K x rows within 64 KB: every K <= 8192 case here at M <= 4, K <= 4096 at M <= 8) and through the rings -
+    against the oracle, one-hot rows bit-exact (tests/kernel.py:30-36), an arbitrary pair codebook included."""
     from flute_amd import dev
     d = env.dev
     cases = [
@@ -455,12 +456,15 @@ def test_persistent_mfma_decode_kernel(env):
                 grid = torch.randn(256, 2).to(dtype)
                 t2 = grid.view(16, 16, 2).contiguous().view(torch.float32)
             What = env.O.dequantize(Q.numpy(), S, t2, bits, g, tile_p).float()
-            for M, ng, vis in [(M, ng, vis) for M in (1, 3, 4, 7, 8, 13, 16) for ng in ((1, 2, 3) if M in (3, 7, 16) else (-1,)) for vis in ((-1, 3) if M in (3, 16) else (-1,))]:
-                ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis)
+            for M, ng, vis, res in [(M, ng, vis, res) for M in (1, 3, 4, 7, 8, 13, 16) for ng in ((1, 2, 3) if M in (3, 7, 16) else (-1,)) for vis in ((-1, 3) if M in (3, 16) else (-1,))
+                                    for res in ((-1, 0) if M in (3, 7) and vis < 0 else (-1,))]:     # res 0: the activation rings also where the activations could be resident
+                ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis, one_shot=res)
                 plan = dev.get_plan(M, N, K, bits, g, tid, env.num_sms, dtype, ovr)
                 nsets = -(-(N // 16) // plan["slabs_per_wave"])
                 assert plan["family"] == 8 and plan["waves"] == 8 and (ng < 0 or plan["slabs_per_wave"] == ng), plan
                 assert plan["grid"] * plan["visits"] >= nsets and plan["grid"] <= nsets and (vis < 0 or plan["visits"] == vis), plan
+                xr = 1 if M <= 4 else 2 if M <= 8 else 4
+                assert plan["one_shot"] == (1 if res != 0 and K * xr <= 8192 and xr <= 2 and not (xr == 1 and plan["slabs_per_wave"] == 3) else 0), plan
                 X = (torch.randn(M, K) / 100).to(dtype)
                 out = dev.qgemm_planned(X.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert out.shape == (M, N)
@@ -472,8 +476,8 @@ def test_persistent_mfma_decode_kernel(env):
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, ng, vis, pair_codebook)
     # automatic on the large layers it was measured on (ids that leave the choice to the planner)
-    for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 8), (4, 14336, 4096, 8), (8, 14336, 4096, 5), (8, 14336, 3584, 8),
-                           (16, 4096, 4096, 7), (4, 4096, 4096, 0), (2, 8192, 8192, 0)):
+    for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 8), (4, 14336, 4096, 8), (8, 14336, 4096, 8), (16, 14336, 4096, 5), (8, 14336, 3584, 8),
+                           (8, 4096, 4096, 8), (16, 4096, 4096, 7), (4, 4096, 4096, 0), (2, 8192, 8192, 0)):
         plan = dev.get_plan(M, N, K, 4, 64, template_ids_for(env.fa, 4, 32)[0], env.num_sms, torch.float16)
         assert env.num_sms != 256 or plan["family"] == fam, (M, N, K, plan)
     # not taken (the override is refused): 17 rows, 2 / 3 bits, 32- / 256-wide groups, K below 1024 or not a multiple of 128, group size 128 with an odd number of groups

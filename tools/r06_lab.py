@@ -96,7 +96,7 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
     nfail = 0
     if os.environ.get("R06_SKIP_CHECK") != "1":
         for (tile_p, g, dtype, K, N) in ((32, 64, f16, 8192, 8192), (32, 64, f16, 4096, 14336), (64, 128, bf16, 8192, 3584), (32, 128, f16, 3584, 4096),
-                                         (32, 64, bf16, 11008, 4096), (64, 64, f16, 1024, 1296 * 4), (32, 64, f16, 14336, 4096), (32, 128, bf16, 1280, 5248), (32, 64, f16, 1152, 2048)):
+                                         (32, 64, bf16, 11008, 4096), (64, 64, f16, 1024, 1296 * 4), (32, 64, f16, 14336, 4096), (32, 128, bf16, 1280, 5248), (32, 64, f16, 1152, 2048), (32, 64, f16, 4096, 4096), (64, 128, bf16, 2048, 2048)):
             torch.manual_seed(K + N)
             if N % (4 * tile_p):
                 continue
@@ -115,7 +115,7 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
                 E[torch.arange(M, device=d), ks] = 1
                 for ng in (1, 2, 3):
                     for vis in (-1, 1, 3, -16):
-                        ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis) if vis != -16 else dev.Overrides(family=8, slabs_per_wave=ng, waves=8)
+                        ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis) if vis != -16 else dev.Overrides(family=8, slabs_per_wave=ng, one_shot=0)
                         try:
                             pl = dev.get_plan(M, N, K, 4, g, tid, L.num_sms, dtype, ovr)
                         except Exception as e:  # noqa: BLE001
@@ -138,7 +138,9 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
         for M in (4, 8, 16):
             L.time_one(M, N, K, 4, f16, None, steps=200, tag="tuned table")
             for ng in (1, 2, 3):
-                L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng, waves=8), steps=200, tag=f"persistm ng={ng}")
+                L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng), steps=200, tag=f"persistm ng={ng}")
+            for ng in (1, 2):
+                L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng, one_shot=0), steps=200, tag=f"persistm ng={ng}rings")
 elif case == "persistm_abl":   # ablation builds of the persistent MFMA decode kernel (-DFLUTE_PM_ABLATE=N)
     for (N, K, ng) in ((28672, 8192, 1), (8192, 28672, 2), (4096, 14336, 1)):
         for M in (4, 16):
