@@ -330,8 +330,8 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     // (sixteen waves per workgroup - four per SIMD, rings three deep - measured slower than eight on every layer: 28672 x 8192 M = 4 32.1 against
     // 31.1 us, 8192^2 13.3 against 11.1, profiles/r06/call33_persistm_16_waves_dropped.log; the kernel keeps the template parameter)
     // (group size 128: a column's scale row must be a whole number of dwords - the macro-step's 4-B scale request)
-    if (bits != 4 || M < 1 || M > 16 || lg < 6 || lg > 7 || K % 128 || (lg == 7 && K % 256) || K < 1024 || N % 16) return FLUTE_ERR_SHAPE;
-    if ((size_t)N * K / 2 >= (size_t)0xfffffff0u || (size_t)N * (size_t)(K >> lg) * 2 >= (size_t)0xfffffff0u || (size_t)M * K * 2 >= (size_t)0xfffffff0u)
+    if ((bits != 4 && bits != 2) || M < 1 || M > 16 || lg < 6 || lg > 7 || K % 128 || (lg == 7 && K % 256) || K < 1024 || N % 16) return FLUTE_ERR_SHAPE;
+    if ((size_t)N * K * bits / 8 >= (size_t)0xfffffff0u || (size_t)N * (size_t)(K >> lg) * 2 >= (size_t)0xfffffff0u || (size_t)M * K * 2 >= (size_t)0xfffffff0u)
         return FLUTE_ERR_SHAPE;
     // Column groups per set (profiles/r06/planner_regret_persistm*.json).  M <= 8: one, unless a wave's stream is long - visits x macro-steps
     // >= 40 at one group per set (8192 x 28672, 28672 x 8192: two groups 28.4 against 31.1 us, 30.3 against 30.9; 8192^2, 16 macro-steps: one group
@@ -357,7 +357,7 @@ int plan_persistm(int bits, int lg, int M, int N, int K, int num_sms, int ng_ovr
     // activations resident in LDS (staged once per workgroup, no activation request in the loop) where 4 xr rows x K fit in 64 KB beside the rest;
     // override one_shot = 0 keeps the rings
     const bool xres = (long)K * xr <= 8192 && xr <= 2 && !(xr == 1 && ng == 3) && xres_ovr != 0;
-    p->lds_bytes = persistm_lds_bytes(ng, xr, 8, xres); p->lut_copies = 32;
+    p->lds_bytes = persistm_lds_bytes(ng, xr, 8, xres, bits); p->lut_copies = 32;
     p->ring_depth = PM_DW; p->visits = visits; p->k_chunks = xr; p->one_shot = xres ? 1 : 0;
     if (oa) { memset(oa, 0, sizeof(*oa)); oa->lg = lg; oa->depth = PM_DW; }
     return FLUTE_OK;
@@ -731,12 +731,17 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
     // (third step, profiles/r06/call37_persistm_resident_activations.log: with the activations RESIDENT in LDS - K * ceil(M / 4) rows within 64 KB - also
     // K = 4096 at M <= 8: 4096^2 M = 8 5.9 -> 5.5, 11008 x 4096 10.9 -> 9.3, 14336 x 4096 11.4 -> 11.3)
     const bool pm_k = K >= 6144 || (K >= 3584 && (M <= 8 || (K != 4096 && K != 2048)));
-    if (ov.family < 0 && bits == 4 && M >= 3 && M <= 16 && (template_id % 4) == 0 && t.sms_multiple == 1 && pm_k && (lg == 6 || lg == 7) &&
-        (size_t)N * K + (M >= 5 ? 1 : 0) > ((size_t)16 << 20) && (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip; 4096^2 itself from M = 5)
+    // 2-bit member (profiles/r06/call38_persistm_2bit.log, us, table's plan -> this): every 2-bit id leaves the choice to the planner and no lean kernel
+    // competes - from K = 3584 and 16 M weights at every 3 <= M <= 16: 4096^2 M = 4 / 16 8.4 / 8.6 -> 5.0 / 6.1, 4096 x 11008 14.1 -> 8.1, 10240 x 8192 18.3 -> 13.8,
+    // 8192 x 28672 30.7 -> 25.8; above M = 8 not where the busiest workgroup pulls more than 28672 k of sixteen-row activations (28672 x 8192: 33.4 against 31.5)
+    const bool pm4 = bits == 4 && (template_id % 4) == 0 && t.sms_multiple == 1 && pm_k && (size_t)N * K + (M >= 5 ? 1 : 0) > ((size_t)16 << 20);
+    const bool pm2 = bits == 2 && K >= 3584 && (size_t)N * K >= ((size_t)16 << 20);
+    if (ov.family < 0 && (pm4 || pm2) && M >= 3 && M <= 16 && (lg == 6 || lg == 7) &&
+        (long)(N / 16) * 2 >= (long)num_sms &&      // (smaller layers: the decode kernels / too few sets for the chip; 4-bit 4096^2 itself from M = 5)
         ov.m_tiles < 0 && ov.waves < 0 && ov.kw < 0 && ov.splitk < 0 && ov.slabs < 0 && ov.m_block < 0 && ov.one_shot < 0 && ov.depth <= 0) {
         flute_plan pm;
         OneArgs pm_oa;
-        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, -1, &pm, &pm_oa) == FLUTE_OK) {
+        if (plan_persistm(bits, lg, M, N, K, num_sms, -1, -1, -1, &pm, &pm_oa) == FLUTE_OK && (bits == 4 || M <= 8 || (long)pm.visits * K <= 28672)) {
             *p = pm;
             if (oa) *oa = pm_oa;
             return FLUTE_OK;
@@ -1368,8 +1373,10 @@ int flute_qgemm_ex(int dtype, int num_bits, int group_size, int hadamard_size, i
     }
 
     if (p.family == kFamilyPersistM) {
-        PersistMKernel fn = dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot)
-                                       : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot);
+        PersistMKernel fn = num_bits == 4 ? (dtype == 0 ? persistm_kernel_b4_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot)
+                                                        : persistm_kernel_b4_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot))
+                                          : (dtype == 0 ? persistm_kernel_b2_f16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot)
+                                                        : persistm_kernel_b2_bf16(t.tile_p, oa.lg, p.slabs_per_wave, p.k_chunks, p.waves, p.one_shot));
         if (!fn) return FLUTE_ERR_TEMPLATE_ID;
         if (ensure_lds(reinterpret_cast<const void*>(fn), p.lds_bytes)) return FLUTE_ERR_LAUNCH;
         const uint32_t* q32 = reinterpret_cast<const uint32_t*>(Q);

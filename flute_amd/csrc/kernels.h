@@ -26,11 +26,13 @@ FastKernel fast_kernel_b4(int dtype, int tile_p, int waves, int kw, int depth, i
 // lean MFMA decode kernel (qgemm_fastm.h): 4 bits, M <= 16, a workgroup = 4 unit rows x all of K = 128 * nm * waves; lg = log2(group size)
 typedef void (*FastMKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, uint64_t*);
 FastMKernel fastm_kernel_b4(int dtype, int tile_p, int waves, int nm, int lg, int ng);   // ng: column groups (4 unit rows each) per workgroup, 1 .. 3
-// persistent MFMA decode kernel (qgemm_persistm.h): 4 bits, M <= 16, K % 128 == 0; lg = log2(group size) (6 / 7), ng: column groups per set (1 .. 3),
+// persistent MFMA decode kernel (qgemm_persistm.h): 4 / 2 bits, M <= 16, K % 128 == 0; lg = log2(group size) (6 / 7), ng: column groups per set (1 .. 3),
 // xr: activation requests per macro-step (1, 2, 4: M <= 4 xr)
 typedef void (*PersistMKernel)(const uint32_t*, const void*, const void*, const uint32_t*, void*, int, int, int, int);
 PersistMKernel persistm_kernel_b4_f16(int tile_p, int lg, int ng, int xr, int waves, int xres);    // waves: 8; xres: activations resident in LDS (K * xr <= 8192; (ng, xr) in (1..2, 1), (1..3, 2))
 PersistMKernel persistm_kernel_b4_bf16(int tile_p, int lg, int ng, int xr, int waves, int xres);
+PersistMKernel persistm_kernel_b2_f16(int tile_p, int lg, int ng, int xr, int waves, int xres);     // 2-bit member (a group = two unit rows of eight columns)
+PersistMKernel persistm_kernel_b2_bf16(int tile_p, int lg, int ng, int xr, int waves, int xres);
 // persistent one-shot decode kernel (qgemm_persist.h): mb rows per pass (1/2), depth = pieces per segment, nsets = register sets
 typedef void (*PersistKernel)(const uint32_t*, const void*, const void*, const uint32_t*, int, int, uint32_t, int, void*, float, int);
 PersistKernel persist_kernel_b4(int dtype, int tile_p, int mb, int depth, int nsets, int had);

@@ -35,7 +35,9 @@
 // Arithmetic contract: as the decode kernels (include/flute_amd.h): fp32 group scale on the group's partial sum (one-hot rows bit-exact).
 // Reference: qgemm_device's main loop for small M (flute/csrc/qgemm_kernel.hpp:617-712); its Stream-K schedule over tiles
 // (tile_scheduler_utils.hpp:460-481) is the flat (set, macro-step) stream here, its fix-up the in-workgroup reduction.
-// Host contract (api.hip: plan_persistm): num_bits = 4, M <= 16, K % 128 == 0, K >= 1024, group size 64 or 128 (128: K % 256 == 0 - a
+// Round 6, last: a 2-bit member (BITS = 2: a group = two unit rows of eight columns; the lookup address is v_bfe + v_lshl_or on a 16-entry image) and the
+// activations RESIDENT in LDS where 4 XR rows x K fit in 64 KB (XRES: staged once per workgroup, no activation request in the loop).
+// Host contract (api.hip: plan_persistm): num_bits = 4 or 2, M <= 16, K % 128 == 0, K >= 1024, group size 64 or 128 (128: K % 256 == 0 - a
 // column's scale row is a whole number of dwords), N % 16 == 0, N * K / 2, N * (K / g) * 2 and M * K * 2 below 2^32 bytes, grid <= sets,
 // XR = 1 / 2 / 4 for M <= 4 / 8 / 16, LDS = persistm_lds_bytes(NG, XR): 32 KB table + rings + 8 NG KB of partial tiles.
 #pragma once
@@ -53,9 +55,10 @@ constexpr int PM_DW = 6;
 __host__ __device__ constexpr int persistm_dx(int ng, int xr, int w = 8, bool xres = false) { return (!xres && (w == 16 || xr == 4 || (xr == 2 && ng == 3))) ? 3 : 6; }
 // M <= 4 (xr = 1): the table image at a 256-B entry stride (64 KB, the upper half of every entry unused) - the v_perm that extracts a lane's
 // byte then IS the lookup address, no shift: one VALU instruction less per pair
-__host__ __device__ constexpr size_t persistm_table_bytes(int xr) { return xr == 1 ? 65536 : 32768; }
-__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8, bool xres = false) {
-    return persistm_table_bytes(xr) + (xres ? (size_t)65536 + (size_t)w * 6 * 256 : (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256)) + (size_t)w * ng * 1024;
+// (2 bits: 16 pair entries x 32 copies = 2 KB)
+__host__ __device__ constexpr size_t persistm_table_bytes(int xr, int bits = 4) { return bits == 2 ? 2048 : (xr == 1 ? 65536 : 32768); }
+__host__ __device__ constexpr size_t persistm_lds_bytes(int ng, int xr, int w = 8, bool xres = false, int bits = 4) {
+    return persistm_table_bytes(xr, bits) + (xres ? (size_t)65536 + (size_t)w * 6 * 256 : (size_t)w * persistm_dx(ng, xr, w) * (xr * 1024 + 256)) + (size_t)w * ng * 1024;
 }
 // the swizzle constant of activation request r (rows 4 r .. 4 r + 3)
 __host__ __device__ constexpr int pm_g(int r) { return (4 - r) & 3; }
@@ -67,14 +70,18 @@ __device__ __forceinline__ void dma4_buf(uint32_t voff, srd_t srd, uint32_t soff
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
 }
 
-template <typename T, int TILEP, int LG, int NG, int XR, int W = 8, bool XRES = false>
+template <typename T, int TILEP, int LG, int NG, int XR, int W = 8, bool XRES = false, int BITS = 4>
 __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const uint32_t* __restrict__ Qp, const void* __restrict__ Sp, const void* __restrict__ Ap,
     const uint32_t* __restrict__ QM2, void* __restrict__ Dp, int N, int K, int M, int nsets) {
     using NT = Num<T>;
     constexpr int DX = persistm_dx(NG, XR, W, XRES), DW = PM_DW, XQ = XR;
     static_assert(W == 8 || W == 16, "waves per workgroup");
-    static_assert(persistm_lds_bytes(NG, XR, W, XRES) <= 160 * 1024, "rings + partial tiles beside the table image");
+    static_assert(persistm_lds_bytes(NG, XR, W, XRES, BITS) <= 160 * 1024, "rings + partial tiles beside the table image");
+    // 2-bit member: a unit row = 8 columns (a word = eight 4-bit pair indices), a group = TWO unit rows; the eight lanes of a unit share its words -
+    // both of their quads hold steps 0 .. 3, so the quad broadcast is the 4-bit one - and a lookup address is v_bfe + v_lshl_or on a 16-entry table
+    static_assert(BITS == 4 || BITS == 2, "3-bit layers: the per-wave MFMA kernel");
+    constexpr int UPG = BITS == 4 ? 4 : 2, CPU = 16 / UPG;          // unit rows per group, columns per unit
     constexpr uint32_t MS_STRIDE = (uint32_t)W * 256u;               // bytes between a wave's consecutive macro-steps in a row
     static_assert(XR == 1 || XR == 2 || XR == 4, "activation requests per macro-step");
     static_assert(LG == 6 || LG == 7, "group size 64 or 128");
@@ -89,8 +96,8 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     constexpr int NXR = ((dbg & 16) || XRES) ? 0 : XQ, NSR = (dbg & 32) ? 0 : 1;
     constexpr int NREQ = NG + NSR + NXR;                            // requests per macro-step: weights, scales, activations
     constexpr uint32_t XSLOT = (uint32_t)XR * 1024u;
-    constexpr bool WIDE = XR == 1;                                  // table image at a 256-B entry stride
-    constexpr uint32_t X_BASE = (uint32_t)persistm_table_bytes(XR), XREG = XRES ? 65536u / W : (uint32_t)DX * XSLOT;
+    constexpr bool WIDE = XR == 1 && BITS == 4;                     // table image at a 256-B entry stride
+    constexpr uint32_t X_BASE = (uint32_t)persistm_table_bytes(XR, BITS), XREG = XRES ? 65536u / W : (uint32_t)DX * XSLOT;
     constexpr uint32_t S_BASE = X_BASE + (uint32_t)W * XREG, SREG = (uint32_t)DX * 256u;
     constexpr uint32_t R_BASE = S_BASE + (uint32_t)W * SREG;
     constexpr int ENT = 256 / W, RUNS = 32 / W;
@@ -102,9 +109,10 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15;                                      // MFMA row (weights) / column (activations)
     const int kg = lane >> 4;                                       // k-chunk of a 32-k step; also: unit of the lane's outputs
-    const int ju = lane & 3;                                        // byte of the packed word = column of the unit
-    const int uu = i16 >> 2;                                        // unit of the group
-    const int nunits = N >> 2;
+    const int ju = lane & 3;                                        // lane of its quad = the step whose words it requests; 4 bits: also the byte of the packed word = column of the unit
+    const int uu = i16 / CPU;                                       // unit of the group
+    const int jcol = i16 % CPU;                                     // column of the unit
+    const int nunits = N / CPU;
     const int nms = K >> 7;                                         // macro-steps of the layer
     const int n_w = (nms - wave + W - 1) / W;                       // ... of this wave per set: w, w + 8, ...
     const int bid = blockIdx.x, grid = gridDim.x;
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const int P = n_items * n_w;                                    // the wave's (set, macro-step) pairs
     const uint32_t row2k = (uint32_t)K * 2u;                        // bytes of a unit row = of an activation row
 
-    const srd_t lut_srd = make_srd(QM2, 1024u);
+    const srd_t lut_srd = make_srd(QM2, BITS == 4 ? 1024u : 64u);
     if constexpr (XRES) {
         // resident activations: macro-step ms of rows 4 r .. 4 r + 3 at X_BASE + ms * XSLOT + r KB (the rings' layout, indexed by the macro-step); the
         // waves share the requests, which are the launch's oldest: every counted wait below covers them, the prologue's barrier publishes them
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
                 dma16_buf((uint32_t)(4 * r + (lane >> 4)) * (uint32_t)K * 2u + (uint32_t)((lane & 15) ^ (4 * (lane >> 4)) ^ pm_g(r)) * 16u, xs0, (uint32_t)ms * 256u,
                           X_BASE + (uint32_t)ms * XSLOT + (uint32_t)r * 1024u);
     }
-    uint32_t lut_v = buf_load4((uint32_t)(wave * ENT + (lane & (ENT - 1))) * 4u, lut_srd);
+    uint32_t lut_v = BITS == 4 ? buf_load4((uint32_t)(wave * ENT + (lane & (ENT - 1))) * 4u, lut_srd) : buf_load4((uint32_t)(lane & 15) * 4u, lut_srd);
     const srd_t q_srd = make_srd(Qp, (uint32_t)((size_t)nunits * row2k));
     const srd_t x_srd = make_srd(Ap, (uint32_t)M * row2k);
     const srd_t s_srd = make_srd(Sp, (uint32_t)((size_t)N * (size_t)(K >> LG) * 2));
@@ -138,19 +146,19 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     const uint32_t sreg = S_BASE + (uint32_t)wave * SREG;
     const uint32_t s_row = (uint32_t)(K >> LG) * 2u;                // bytes of a column's scale row
     auto scale_voff = [&](int set) {                                // lane = column 4 (4 g + u) + r of the set
-        const int unit = set * (4 * NG) + (lane >> 2);
-        const int col = (unit / TILEP) * (4 * TILEP) + (unit % TILEP) + (lane & 3) * TILEP;
+        const int unit = set * (UPG * NG) + (lane >> 4) * UPG + (lane & 15) / CPU;
+        const int col = (unit / TILEP) * (CPU * TILEP) + (unit % TILEP) + ((lane & 15) % CPU) * TILEP;
         return (lane < 16 * NG && unit < nunits) ? (uint32_t)col * s_row : 0xfffffff0u;
     };
 
     // ---- the three cursors of the flat stream (request weights / request scales + activations / compute), kept as countdowns and
     // additive offsets: every quantity below is wave-uniform and lives in SGPRs (the first version's multiplications and comparisons per
     // request were ~170 scalar instructions per macro-step, more than the VALU work) ----
-    const uint32_t set_units = (uint32_t)grid * (4 * NG);           // unit rows between a workgroup's consecutive sets
+    const uint32_t set_units = (uint32_t)grid * (UPG * NG);         // unit rows between a workgroup's consecutive sets
     const uint32_t w_jump = set_units * row2k - (uint32_t)n_w * MS_STRIDE;      // from a set's last macro-step to the next set's first
-    uint32_t w_so = (uint32_t)(bid * (4 * NG)) * row2k + (uint32_t)wave * 256u;
-    int w_left = n_w, w_u0 = bid * (4 * NG);
-    auto groups_at = [&](int u0, int sets_left) { const int gl = (nunits - u0) >> 2; return sets_left > 0 ? (gl < NG ? gl : NG) : 0; };
+    uint32_t w_so = (uint32_t)(bid * (UPG * NG)) * row2k + (uint32_t)wave * 256u;
+    int w_left = n_w, w_u0 = bid * (UPG * NG);
+    auto groups_at = [&](int u0, int sets_left) { const int gl = (nunits - u0) / UPG; return sets_left > 0 ? (gl < NG ? gl : NG) : 0; };
     int w_sets = n_items, w_ng = groups_at(w_u0, w_sets);           // valid groups of the cursor's set (0: past the last pair)
     uint32_t x_so = (uint32_t)wave * 256u;
     int x_left = n_w, x_sets = n_items, x_set = bid;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
             constexpr int g = decltype(g_tag)::value;
             srd_t d = q_srd;
             d.z = (!(dbg & 8) && g < w_ng) ? d.z : 0;
-            const uint32_t so = w_so + (uint32_t)g * 4u * row2k;
+            const uint32_t so = w_so + (uint32_t)(g * UPG) * row2k;
             ring16_t& dst = q[slot][g];
             const uint32_t vo = q_vo;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(d), "s"(so) : "memory");
@@ -232,7 +240,10 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
 
     // ---- table image: entry e at [128 e, 128 e + 128) (WIDE: [256 e, 256 e + 128)): a wave writes RUNS runs of 8 entries (1 KiB, lane-linear) ----
     vm_wait_regs<DW * NG + DX * (NSR + NXR)>(lut_v);
-    {
+    if constexpr (BITS == 2) {                                      // 16 entries: waves 0 / 1 write eight each
+        const uint32_t te = (uint32_t)__builtin_amdgcn_ds_bpermute(((wave & 1) * 8 + (lane >> 3)) * 4, (int)lut_v);
+        if (wave < 2) *reinterpret_cast<uint4*>(smem + (uint32_t)wave * 1024u + (uint32_t)lane * 16u) = make_uint4(te, te, te, te);
+    } else {
         uint32_t te[RUNS];
 #pragma unroll
         for (int u = 0; u < RUNS; ++u) te[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((u * 8 + (lane >> 3)) * 4, (int)lut_v);
@@ -247,6 +258,7 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
     // ---- per-lane LDS addresses ----
     const uint32_t lane_off2 = (uint32_t)(lane & 31) * (WIDE ? 4u : 8u);     // twice the copy offset (the address is halved after the v_perm); WIDE: the offset itself
     const uint32_t sel = 0x0c0c0400u | ((uint32_t)ju << 8);         // {copy offset x 2, byte ju of the word, 0, 0}
+    const uint32_t nib_shift = (uint32_t)jcol * 4u, lane_off4 = (uint32_t)(lane & 31) * 4u;      // 2 bits: the column's nibble, the copy offset
     // activation fragment of step s: row i16 = 4 r + mm, chunk 4 s + kg -> request r's KB, position 16 mm + 4 (s ^ mm) + (kg ^ g(r))
     uint32_t xa[4];
     {
@@ -274,7 +286,8 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t wsrc = (uint32_t)__builtin_amdgcn_mov_dpp((int)q[qs][g][c], s * 0x55, 0xF, 0xF, true);       // quad_perm [s, s, s, s]
-                ad[c] = WIDE ? __builtin_amdgcn_perm(wsrc, lane_off2, sel) : __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
+                if constexpr (BITS == 2) ad[c] = (__builtin_amdgcn_ubfe(wsrc, nib_shift, 4u) << 7) | lane_off4;
+                else ad[c] = WIDE ? __builtin_amdgcn_perm(wsrc, lane_off2, sel) : __builtin_amdgcn_perm(wsrc, lane_off2, sel) >> 1;
             }
             asm volatile("" : "+v"(ad[0]), "+v"(ad[1]), "+v"(ad[2]), "+v"(ad[3]));
 #pragma unroll
@@ -347,8 +360,9 @@ __global__ __launch_bounds__(W * 64) void qgemm_persistm_kernel(
                 float sum = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < W; ++w2) sum += __builtin_bit_cast(float, lds_ld32(R_BASE + (uint32_t)(w2 * NG + g) * 1024u + (uint32_t)f * 4u));
-                const int unit = set * (4 * NG) + 4 * g + (ls >> 4);
-                const int col = (unit / TILEP) * (4 * TILEP) + (unit % TILEP) + r * TILEP;
+                const int c16 = 4 * (ls >> 4) + r;                   // MFMA weight row = column 16 g + c16 of the set
+                const int unit = set * (UPG * NG) + UPG * g + c16 / CPU;
+                const int col = (unit / TILEP) * (CPU * TILEP) + (unit % TILEP) + (c16 % CPU) * TILEP;
                 if (m < M && unit < nunits) reinterpret_cast<uint16_t*>(Dp)[(size_t)m * N + col] = NT::from_float(sum);
             }
         }

@@ -86,7 +86,7 @@ typedef struct flute_plan {
                             7 = lean MFMA decode kernel (qgemm_fastm.h, round 5: 4 bits, 5 <= M <= 16, K in {2048, 4096}, a
                             workgroup = 4 unit rows x all of K, N / 16 workgroups of 8 waves between half a round and one
                             round of the CUs, 32 KB + 32 copies x 4 KB of LDS = 160 KB; what it cannot take falls back),
-                            8 = persistent MFMA decode kernel (qgemm_persistm.h, round 6: 4 bits, 3 <= M <= 16, K % 128 == 0, group size
+                            8 = persistent MFMA decode kernel (qgemm_persistm.h, round 6: 4 or 2 bits, 3 <= M <= 16, K % 128 == 0, group size
                             64 / 128; `grid` workgroups of 8 waves stream `visits` sets of slabs_per_wave column groups (16 columns each) x
                             all of K, k_chunks = 1 / 2 / 4 activation requests per 128-k macro-step for M <= 4 / 8 / 16; automatic under the
                             ids that leave the choice to the planner for layers above 16 M weights with K >= 6144, K >= 3584 at M <= 8 or
@@ -129,7 +129,7 @@ typedef struct flute_plan {
  *                   row tiles per XCD group of the block order; waves must be 12 or automatic - the variant without loader
  *                   waves was dropped in round 6);
  *                   7 lean MFMA decode kernel (4 bits, 5 <= M <= 16, K in {2048, 4096}; falls back where it does not apply);
- *                   8 persistent MFMA decode kernel (4 bits, M <= 16, K % 128 == 0, K >= 1024, group size 64 / 128; slabs_per_wave 1 .. 3:
+ *                   8 persistent MFMA decode kernel (4 / 2 bits, M <= 16, K % 128 == 0, K >= 1024, group size 64 / 128; slabs_per_wave 1 .. 3:
  *                   column groups per set, m_tiles: sets per workgroup, one_shot 0: activation rings also where the activations could be resident;
  *                   refused - FLUTE_ERR_SHAPE - where it does not apply);
  *                   0 decode kernels also at M = 3, 4 (2- / 4-bit; automatic: M <= 2, and M <= 4 for

@@ -80,6 +80,8 @@ def test_plan_families_and_invariants():
                 want = 7                             # 4 bits, K = 4096, one round of 4-unit workgroups: the lean MFMA decode kernel (round 5)
             if bits == 4 and 5 <= M <= 8:
                 want = 8                             # ... up to eight rows the persistent MFMA decode kernel with the activations resident in LDS (round 6: 5.5 against 5.9 us)
+            if bits == 2 and 3 <= M <= 16:
+                want = 8                             # 2 bits: the persistent MFMA decode kernel's 2-bit member from three rows (round 6: M = 4 8.4 -> 5.0 us, M = 16 8.6 -> 6.1)
             assert p.family == want, (bits, M, p.family)    # (N = 4096: too few output blocks for the 2- / 4-bit block kernels)
             if p.family == 7:
                 assert (p.grid, p.waves, p.block, p.lds_bytes, p.splitk, p.workspace_needed) == (256, 8, 512, 32768 + 32 * 4096, 1, 0)
@@ -335,17 +337,18 @@ def test_plan_invariants_over_random_shapes():
             assert ng in (1, 2, 3) and p.grid == -(-(N // 16) // ng) and p.grid <= num_sms and (ng == 1 or -(-(N // 16) // (ng - 1)) > num_sms), what
             assert p.waves == 8 and p.lds_bytes == 32768 + 32 * K and p.ring_depth * 128 * 8 == K, what
         elif p.family == 8:                                       # persistent MFMA decode kernel (qgemm_persistm.h's host contract)
-            assert bits == 4 and 3 <= M <= 16 and K % 128 == 0 and g in (64, 128) and (g == 64 or K % 256 == 0) and tid % 4 == 0, what
-            assert K >= 6144 or (K >= 3584 and (M <= 8 or K not in (2048, 4096))), what
+            assert bits in (2, 4) and 3 <= M <= 16 and K % 128 == 0 and g in (64, 128) and (g == 64 or K % 256 == 0) and (bits == 2 or tid % 4 == 0), what
+            assert K >= 6144 or (K >= 3584 and (bits == 2 or M <= 8 or K not in (2048, 4096))), what
             ng, xr = p.slabs_per_wave, p.k_chunks                  # column groups per set, activation requests per macro-step
             nsets = -(-(N // 16) // ng)
             assert ng in (1, 2, 3) and xr == (1 if M <= 4 else 2 if M <= 8 else 4) and p.grid <= min(num_sms, nsets) and p.grid * p.visits >= nsets, what
-            assert (p.visits - 1) * p.grid < nsets and N * K + (1 if M >= 5 else 0) > 16 << 20 and (N // 16) * 2 >= num_sms, what
+            assert (p.visits - 1) * p.grid < nsets and N * K + (1 if M >= 5 or bits == 2 else 0) > 16 << 20 and (N // 16) * 2 >= num_sms, what
+            assert bits == 4 or M <= 8 or p.visits * K <= 28672, what
             dx = 3 if (xr == 4 or (xr == 2 and ng == 3)) else 6
             xres = p.one_shot                                      # activations resident in LDS: 4 xr rows x K within 64 KB
             assert xres == (1 if (K * xr <= 8192 and xr <= 2 and not (xr == 1 and ng == 3)) else 0), what
             rings = 65536 + 8 * 6 * 256 if xres else 8 * dx * (xr * 1024 + 256)
-            assert p.waves == 8 and p.lds_bytes == (65536 if xr == 1 else 32768) + rings + 8 * ng * 1024 and N * K // 2 < 2 ** 32, what
+            assert p.waves == 8 and p.lds_bytes == (2048 if bits == 2 else 65536 if xr == 1 else 32768) + rings + 8 * ng * 1024 and N * K // 2 < 2 ** 32, what
         elif p.family == 2:                                       # per-wave MFMA kernel
             assert p.m_block in (1, 2, 4) and p.m_tiles in (1, 2, 4) and p.slabs_per_wave in (1, 2), what
             assert p.slabs_per_wave == 1 or (bits == 4 and p.m_block == 1), what

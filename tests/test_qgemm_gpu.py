@@ -432,7 +432,7 @@ def test_lean_mfma_decode_kernel(env):
 
 
 def test_persistent_mfma_decode_kernel(env):
-    """The persistent MFMA decode kernel (qgemm_persistm.h, round 6; family 8): workgroups stream column-group sets x all of K, the eight
+    """The persistent MFMA decode kernel (qgemm_persistm.h, round 6; family 8; 4-bit and 2-bit members): workgroups stream column-group sets x all of K, the eight
     waves of a workgroup take the 128-k macro-steps w, w + 8, ... - every (group size, TileP, dtype), one / two / three column groups per
     set, one / two / four activation requests per macro-step (M <= 4 / 8 / 16), one and several sets per workgroup (override m_tiles), K
     that leaves the waves unequal shares (1152 = 9 macro-steps, 1280 = 10, 3584 = 28), layers whose last set holds fewer groups (N = 5248:
@@ -441,20 +441,21 @@ def test_persistent_mfma_decode_kernel(env):
     from flute_amd import dev
     d = env.dev
     cases = [
-        # tile_p, g, dtype, K, N
-        (32, 64, torch.float16, 8192, 1024), (64, 128, torch.bfloat16, 8192, 2048), (32, 64, torch.bfloat16, 1152, 5248),
-        (64, 64, torch.float16, 3584, 1024), (32, 128, torch.float16, 1280, 5248), (32, 64, torch.float16, 11008, 512),
+        # bits, tile_p, g, dtype, K, N
+        (4, 32, 64, torch.float16, 8192, 1024), (4, 64, 128, torch.bfloat16, 8192, 2048), (4, 32, 64, torch.bfloat16, 1152, 5248),
+        (4, 64, 64, torch.float16, 3584, 1024), (4, 32, 128, torch.float16, 1280, 5248), (4, 32, 64, torch.float16, 11008, 512),
+        # the 2-bit member (a group = two unit rows of eight columns, 16-entry pair table)
+        (2, 32, 64, torch.float16, 8192, 1024), (2, 64, 128, torch.bfloat16, 4096, 2048), (2, 32, 64, torch.bfloat16, 1152, 5376), (2, 32, 128, torch.float16, 3584, 768),
     ]
-    for (tile_p, g, dtype, K, N) in cases:
-        bits = 4
+    for (bits, tile_p, g, dtype, K, N) in cases:
         W, Q, S, table, table2 = make_case(env, bits, tile_p, g, dtype, K, N, seed=K % 79 + N % 13 + g)
         tid = template_ids_for(env.fa, bits, tile_p)[0]
         Qd, Sd, td = Q.to(d), S.to(d), table.to(d)
         for pair_codebook in (False, True):
             t2 = table2
             if pair_codebook:
-                grid = torch.randn(256, 2).to(dtype)
-                t2 = grid.view(16, 16, 2).contiguous().view(torch.float32)
+                grid = torch.randn(4 ** bits, 2).to(dtype)
+                t2 = grid.view(2 ** bits, 2 ** bits, 2).contiguous().view(torch.float32)
             What = env.O.dequantize(Q.numpy(), S, t2, bits, g, tile_p).float()
             for M, ng, vis, res in [(M, ng, vis, res) for M in (1, 3, 4, 7, 8, 13, 16) for ng in ((1, 2, 3) if M in (3, 7, 16) else (-1,)) for vis in ((-1, 3) if M in (3, 16) else (-1,))
                                     for res in ((-1, 0) if M in (3, 7) and vis < 0 else (-1,))]:     # res 0: the activation rings also where the activations could be resident
@@ -476,12 +477,15 @@ def test_persistent_mfma_decode_kernel(env):
                 out1 = dev.qgemm_planned(E.to(d), Qd, Sd, td, t2.to(d), env.ws, bits, g, tid, env.num_sms, ovr).cpu()
                 assert torch.equal(out1.float(), What[ks].to(dtype).float()), ("one-hot", tile_p, g, dtype, K, N, M, ng, vis, pair_codebook)
     # automatic on the large layers it was measured on (ids that leave the choice to the planner)
+    for (M, N, K, fam) in ((4, 4096, 4096, 8), (16, 4096, 4096, 8), (16, 8192, 28672, 8), (16, 28672, 8192, 2), (2, 4096, 4096, 0)):
+        plan = dev.get_plan(M, N, K, 2, 64, template_ids_for(env.fa, 2, 32)[0], env.num_sms, torch.float16)
+        assert env.num_sms != 256 or plan["family"] == fam, (2, M, N, K, plan)
     for (M, N, K, fam) in ((4, 8192, 8192, 8), (16, 8192, 8192, 8), (8, 4096, 14336, 8), (16, 28672, 8192, 8), (4, 14336, 4096, 8), (8, 14336, 4096, 8), (16, 14336, 4096, 5), (8, 14336, 3584, 8),
                            (8, 4096, 4096, 8), (16, 4096, 4096, 7), (4, 4096, 4096, 0), (2, 8192, 8192, 0)):
         plan = dev.get_plan(M, N, K, 4, 64, template_ids_for(env.fa, 4, 32)[0], env.num_sms, torch.float16)
         assert env.num_sms != 256 or plan["family"] == fam, (M, N, K, plan)
-    # not taken (the override is refused): 17 rows, 2 / 3 bits, 32- / 256-wide groups, K below 1024 or not a multiple of 128, group size 128 with an odd number of groups
-    for (M, K, bits, g) in ((17, 8192, 4, 64), (8, 8192, 2, 64), (8, 8192, 3, 64), (8, 8192, 4, 32), (8, 8192, 4, 256), (8, 512, 4, 64), (8, 4096 + 64, 4, 64), (8, 1152, 4, 128)):
+    # not taken (the override is refused): 17 rows, 3 bits, 32- / 256-wide groups, K below 1024 or not a multiple of 128, group size 128 with an odd number of groups
+    for (M, K, bits, g) in ((17, 8192, 4, 64), (17, 8192, 2, 64), (8, 8192, 3, 64), (8, 8192, 4, 32), (8, 8192, 4, 256), (8, 512, 4, 64), (8, 4096 + 64, 4, 64), (8, 1152, 4, 128)):
         try:
             plan = dev.get_plan(M, 4096, K, bits, g, template_ids_for(env.fa, bits, 32)[0], env.num_sms, torch.float16, dev.Overrides(family=8))
         except Exception:  # noqa: BLE001

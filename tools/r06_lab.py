@@ -141,6 +141,56 @@ elif case == "persistm":  # persistent MFMA decode kernel (family 8): check agai
                 L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng), steps=200, tag=f"persistm ng={ng}")
             for ng in (1, 2):
                 L.time_one(M, N, K, 4, f16, dict(family=8, slabs_per_wave=ng, one_shot=0), steps=200, tag=f"persistm ng={ng}rings")
+elif case == "persistm2":  # the 2-bit member of the persistent MFMA decode kernel: check against fp32 + one-hot rows, then time against the table's plan
+    import json
+    from flute_amd import dev, utils
+    d = L.d
+    nfail = 0
+    for (tile_p, g, dtype, K, N) in ((32, 64, f16, 8192, 8192), (32, 64, f16, 4096, 14336), (64, 128, bf16, 8192, 3584), (32, 128, f16, 3584, 4096),
+                                     (32, 64, bf16, 11008, 4096), (64, 64, f16, 1024, 1024 * 5), (32, 64, f16, 14336, 4096), (32, 128, bf16, 1280, 5376),
+                                     (32, 64, f16, 1152, 2048), (32, 64, f16, 4096, 4096)):
+        torch.manual_seed(K + N)
+        if N % (8 * tile_p):
+            continue
+        W = torch.randint(0, 4, (K, N), dtype=torch.uint8, device=d)
+        S = torch.randn(N, K // g, device=d).to(dtype)
+        table = torch.randn(4, device=d).to(dtype)
+        table2 = utils.make_qmap2_from_qmap(table)
+        tid = L.tid_of(2, tile_p)
+        Q = utils.pack(W, 2, [tid], L.num_sms)
+        What = table[W.long()] * torch.repeat_interleave(S, g, dim=1).T
+        for M in (3, 5, 11, 16):
+            X = (torch.randn(M, K, device=d) / 100).to(dtype)
+            ref = X.float() @ What.float()
+            ks = torch.randint(0, K, (M,), device=d)
+            E = torch.zeros(M, K, device=d, dtype=dtype)
+            E[torch.arange(M, device=d), ks] = 1
+            for ng in (1, 2, 3):
+                for (vis, res) in ((-1, -1), (3, -1), (-1, 0)):
+                    ovr = dev.Overrides(family=8, slabs_per_wave=ng, m_tiles=vis, one_shot=res)
+                    try:
+                        pl = dev.get_plan(M, N, K, 2, g, tid, L.num_sms, dtype, ovr)
+                    except Exception as e:  # noqa: BLE001
+                        print(json.dumps({"kind": "check_persistm2", "N": N, "K": K, "ng": ng, "vis": vis, "error": str(e)[:100]}), flush=True)
+                        nfail += 1
+                        continue
+                    o = dev.qgemm_planned(X, Q, S, table, table2, L.ws, 2, g, tid, L.num_sms, ovr)
+                    o1 = dev.qgemm_planned(E, Q, S, table, table2, L.ws, 2, g, tid, L.num_sms, ovr)
+                    err = ((o.float() - ref).norm() / ref.norm()).item()
+                    ok = err < (1e-3 if dtype == f16 else 4e-3) and bool(torch.equal(o1, What[ks]))
+                    if not ok:
+                        nfail += 1
+                        print(json.dumps({"kind": "check_persistm2", "N": N, "K": K, "g": g, "dtype": str(dtype), "M": M, "ng": ng, "vis": vis, "res": res, "grid": pl["grid"],
+                                          "err": err, "onehot": bool(torch.equal(o1, What[ks]))}), flush=True)
+        del W, S, Q, What
+        torch.cuda.empty_cache()
+    print(json.dumps({"kind": "check_persistm2_summary", "failed": nfail}), flush=True)
+    shapes = ((28672, 8192), (8192, 28672), (8192, 8192), (14336, 4096), (4096, 14336), (10240, 8192), (4096, 11008), (3584, 14336), (11008, 4096), (4096, 4096))
+    for (N, K) in shapes:
+        for M in (4, 8, 16):
+            L.time_one(M, N, K, 2, f16, None, steps=200, tag="tuned table")
+            for ng in (1, 2, 3):
+                L.time_one(M, N, K, 2, f16, dict(family=8, slabs_per_wave=ng), steps=200, tag=f"persistm ng={ng}")
 elif case == "persistm_abl":   # ablation builds of the persistent MFMA decode kernel (-DFLUTE_PM_ABLATE=N)
     for (N, K, ng) in ((28672, 8192, 1), (8192, 28672, 2), (4096, 14336, 1)):
         for M in (4, 16):

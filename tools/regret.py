@@ -57,7 +57,8 @@ def candidates(bits, M):
     if 3 <= M <= 16 and bits == 4:
         c += [dict(family=5, splitk=sk) for sk in (1, 2, 4, 8)]
         c += [dict(family=7, slabs_per_wave=ng) for ng in (1, 2, 3)]          # lean MFMA decode kernel: column groups per workgroup (round 6)
-        c += [dict(family=8, slabs_per_wave=ng) for ng in (1, 2, 3)]          # persistent MFMA decode kernel: column groups per set (round 6)
+    if 3 <= M <= 16 and bits in (2, 4):
+        c += [dict(family=8, slabs_per_wave=ng) for ng in (1, 2, 3)]          # persistent MFMA decode kernel (4- and 2-bit members): column groups per set (round 6)
     if bits == 3 and 17 <= M <= 64:
         c += [dict(family=3, m_block=4), dict(family=3, m_block=2)]
     if bits == 3 and M > 64:
