@@ -534,6 +534,9 @@ def main():
                 ("W4G64 fp16 M=8 K=28672 N=8192 (persistent MFMA decode kernel)", 8, 8192, 28672, 4, dtype, 0),
                 ("W4G64 fp16 M=4 K=14336 N=4096 (persistent MFMA decode kernel)", 4, 4096, 14336, 4, dtype, 0),
                 ("W4G64 fp16 M=16 K=8192 N=28672 (persistent MFMA decode kernel)", 16, 28672, 8192, 4, dtype, 0),
+                ("W4G64 fp16 M=8 K=4096 N=4096 (persistent MFMA decode kernel, activations resident in LDS)", 8, 4096, 4096, 4, dtype, 0),
+                ("W2G64 fp16 M=4 K=4096 N=4096 (persistent MFMA decode kernel, 2-bit member)", 4, 4096, 4096, 2, dtype, 0),
+                ("W2G64 fp16 M=16 K=11008 N=4096 (persistent MFMA decode kernel, 2-bit member)", 16, 4096, 11008, 2, dtype, 0),
                 ("W4G64 fp16 M=64 K=8192 N=28672 (per-wave MFMA kernel, two slabs per wave)", 64, 28672, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=1 K=8192 N=3584 = TP-8 column shard of 8192x28672 (configs[3])", 1, 3584, 8192, 4, dtype, 0),
                 ("W4G64 fp16 M=1 K=3584 N=4096 pair codebook + hadamard_size=512 (configs[4], Gemma-2-9B)", 1, 4096, 3584, 4, dtype, 512)):
