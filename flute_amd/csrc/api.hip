@@ -904,6 +904,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
                 // M = 64 .. 96 on layers up to 14336 columns; 490 .. 570 on 28672 columns (two slabs per wave, every CU busy)
                 wave_tf = std::min(300.0, 5.5 * M) * (bf ? 0.8 : 1.0);
                 if (N >= 16384) wave_tf *= 1.8;
+                // (the 2-bit factor holds here too - it was applied above the branch only: 2-bit M = 48 on 4096^2 kept the per-wave kernel x 4 K slices,
+                // 15.0 us, where 64 x 64 tiles x 4 slices run 11.1: profiles/r06_planner_regret_final_tree_between.json)
+                if (bits == 2) wave_tf *= 0.65;
             }
             alt_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
         }
@@ -916,7 +919,9 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
         // 2048 x 4096 15.8 / 19.9, M = 256 on 2048 x 8192 18.0 / 26.6, M = 48 on 3584 x 14336 16.7 / 21.6, M = 33 on 8192^2 17.7 / 26.1)
         if (plan_splitk(bits, lg, M, N, K, num_sms, ov, workspace_bytes, &q, 0, &sk_us) == FLUTE_OK &&
             sk_us < ((q.kw == 4 && (long)q.grid * 2 >= (long)num_sms) ? alt_us + 4.0 : 0.92 * alt_us) &&
-            (long)q.grid <= (long)num_sms && q.lds_bytes <= (size_t)kMaxLds) {
+            (long)q.grid <= (bits == 2 && M <= 64 ? 2L : 1L) * (long)num_sms && q.lds_bytes <= (size_t)kMaxLds) {
+            // (2-bit layers up to M = 64: also two rounds - 28672 x 8192 M = 33 / 48 / 64: 448 workgroups of 64 x 128 tiles x 2 slices 46.6 / 47.8 / 49.3 us
+            // against the per-wave kernel's 61.3 / 61.5 / 62.3, profiles/r06/planner_regret_b2_m33_96_after_2bit_rate_fix.json)
             *p = q;
             return FLUTE_OK;
         }
