@@ -826,7 +826,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // 38.5 us, 28672x8192 86.9 vs 105.7, 4096x14336 31.8 vs 35.4; slower below M = 33 and on 4096^2 (fixed
             // costs of ~8 us per call: prologue, fp32 slabs, reduce launch)
             blk_cfg = 12;
-        } else if (M >= 256 || (bits == 3 && M > 64)) {          // (3 bits from M = 65: the K-split candidates below)
+        } else if (M >= 256 || (bits == 3 && M > 64) || (bits != 3 && M > 128)) {          // (3 bits from M = 65: the K-split candidates below; 2 / 4 bits from M = 129: 128-row blocks on the
+            // widest layers - 2-bit 28672 x 8192 at M = 192 ran 210 us on the per-wave kernel, 125 on 128-row blocks, profiles/r06/planner_regret_bits_4_2_m96_to_768_unswept_batch_sizes.json)
             const bool bf = dtype == FLUTE_BF16;
             auto block_us = [&](long tiles, double alone, double busy) {
                 const long whole = tiles / num_sms, rest = tiles % num_sms;       // full rounds + a last partial one
