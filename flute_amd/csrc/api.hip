@@ -643,6 +643,11 @@ int plan_stream(int dtype, int bits, int lg, int M, int N, int K, int num_sms, c
     return FLUTE_OK;
 }
 
+// Per-wave MFMA kernel (2 / 4 bits), TFLOP/s by batch size, 128 <= M < 512 (end of round 6, profiles/r06/planner_regret_bits_4_2_m128_to_512_end_of_round.json:
+// measured 295 / 345 at M = 160 / 192 on 11008 x 4096, 426 / 493 at M = 320 / 384 on 4096^2 - the "520 at M = 256, 465 below" it replaces kept the per-wave
+// kernel at M = 160 / 192 / 320 on 11008 x 4096, 14336 x 4096, 14336 x 3584, 3584 x 14336, 3584 x 8192 where split-K tiles run 30 - 70 % faster)
+double wave_tf_mid(int M, int bits, bool bf) { return (300.0 + 0.75 * (M - 128)) * (bf ? 0.8 : 1.0) * (bits == 2 ? 0.65 : 1.0); }
+
 // ids whose last digit leaves the kernel choice to the planner: 4-bit QuantMapMode digit 0, every 2- / 3-bit id
 bool auto_digit_sk(int bits, int template_id) { return bits != 4 || (template_id % 4) == 0; }
 
@@ -847,7 +852,8 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // (3 bits, round 4: 14336 x 3584 M = 256 runs at 305, modelled 370 kept it off the 128-row blocks: 86.4 against 70.3 us; round 5's
             // regret sweep, fp16: 3584 x 8192 M = 256 293, 14336 x 3584 M = 128 276, 8192^2 M = 96 253 - fewer rows, fewer MFMAs per lookup)
             const double wave_tf = (bits == 3) ? (bf ? 290.0 : 300.0) * (M >= 256 ? 1.0 : 0.6 + 0.4 * M / 256.0)
-                                   : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl)) * (bits == 2 ? 0.65 : 1.0);   // (2 bits: see below)
+                                   : (M < 512 ? wave_tf_mid(M, bits, bf)
+                                              : (bf ? std::min(560.0, 400.0 + 55.0 * dbl) : std::min(730.0, 520.0 + 55.0 * dbl)) * (bits == 2 ? 0.65 : 1.0));   // (2 bits: see below)
             const double wave_us = 2.0 * M * (double)N * K / (wave_tf * 1e6);
             if (t256 <= t128 && t256 < wave_us) blk_cfg = 4;
             else if (t128 < t256 && t128 < wave_us) blk_cfg = 5;
@@ -900,6 +906,7 @@ int make_plan_uncached(int dtype, int bits, int group, int M, int N, int K, int 
             // (2-bit layers: twice the lookups per byte - the per-wave kernel ran M = 384 on 4096^2 at 316 TFLOP/s where the 4-bit layer runs 503:
             // profiles/r06_planner_regret_between_final.json)
             if (bits == 2) wave_tf *= 0.65;
+            if (M >= 128 && M < 512) wave_tf = wave_tf_mid(M, bits, bf);
             if (M < 128) {
                 // per-wave kernel below M = 128 (measured fp16, tools/time_cases.py): 220 .. 280 TFLOP/s at M = 48, 270 .. 350 at
                 // M = 64 .. 96 on layers up to 14336 columns; 490 .. 570 on 28672 columns (two slabs per wave, every CU busy)
